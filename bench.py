@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: WaveNet training-step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one full data-parallel training step (src/model.py:309-348): shift-by-one, forward,
+loss, backward, SUM all-reduce of the flat gradient over RCCL, per-tensor clipnorm + Keras Adam
+(train.py:225-226) on one batch of synthetic 16 kHz mu-law waveforms already resident in HBM.
+Workload = BASELINE.json configs[1] (30-layer 3x10 mu-law-256 WaveNet, 64 residual / 256 skip
+channels, batch 8 x 16000 per GPU); N GPUs run configs[2]'s data-parallel form (weak scaling:
+per-GPU batch fixed at 8, global batch 8 N).  The metric-only sample_waveform call of the
+reference (src/model.py:338) is excluded.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     -- the fused residual-block forward kernel (the "dilated-conv forward" of
+                  north_star): algorithmic bytes 4 B T (2R + S) per launch / live HIP-event
+                  time per launch, against the 8 TB/s HBM3E peak
+  cpu_baseline -- the CPU oracle (restated reference, PyTorch CPU) timed on this host's cores
+                  on a bounded sample (configs[0]: 10-layer, 32 ch, 1 x 16000)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CFG2 = dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024,
+            final_layers_channels=[128, 256], activation='leaky_relu', bits=8)
+CFG1 = dict(blocks=10, channels=32, dilation_bound=1024, final_layers_channels=[], bits=8)
+
+
+def cpu_baseline(budget_s: float = 20.0):
+  """Restated-reference CPU baseline: oracle train step on configs[0] (1 x 16000)."""
+  import torch
+  from oracle import wavenet_oracle as O
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  ocfg = O.OracleConfig(**CFG1)
+  params = O.init_params(ocfg, seed=0, bias_range=0.0)
+  m = [torch.zeros_like(p) for p in params]
+  v = [torch.zeros_like(p) for p in params]
+  x = O.synthetic_waveform(1, 16001, seed=1234)
+  t0 = time.time()
+  _, params, m, v = O.train_step(x, params, m, v, 1, ocfg)          # warm-up
+  one = time.time() - t0
+  n = max(1, min(100, int(budget_s / max(one, 1e-3)) - 1))
+  t0 = time.time()
+  for i in range(n):
+    _, params, m, v = O.train_step(x, params, m, v, i + 2, ocfg)
+  dt = (time.time() - t0) / n
+  return {'value': 16000.0 / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+          'sample': f'{n} train steps of configs[0] (10-layer, 32 ch, head [], batch 1x16000) '
+                    f'with the PyTorch-CPU oracle, {dt * 1e3:.0f} ms/step'}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (utterances)')
+  ap.add_argument('--length', type=int, default=16000, help='predicted samples per utterance')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-budget', type=float, default=20.0)
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from wavenets_amd import WaveNet, Adam, _lib
+  from oracle import wavenet_oracle as O     # synthetic input generator + cpu_baseline leg only
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.gpus > 1 and world != args.gpus:
+    raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=dev)
+
+  B, T = args.batch, args.length
+  model = WaveNet(**CFG2, device=dev, seed=0)          # glorot kernels, zero biases, same on all ranks
+  model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
+  x = O.synthetic_waveform(B, T + 1, seed=1234 + rank).to(dev)
+
+  def sync():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    model.train_step(x)
+  L = _lib.lib()
+  nblk = CFG2['blocks']
+  _lib.check(L.wn_prof_enable(model._plan, nblk * min(args.steps, 20)))
+  sync()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    logs = model.train_step(x)
+  sync()
+  dt = time.perf_counter() - t0
+  n_l, avg_ms = C.c_int32(), C.c_float()
+  _lib.check(L.wn_prof_read(model._plan, C.byref(n_l), C.byref(avg_ms)))
+  _lib.check(L.wn_prof_enable(model._plan, 0))
+
+  t = torch.tensor([dt], dtype=torch.float64, device=dev)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  dt = float(t.item())
+  ms_per_step = dt / args.steps * 1e3
+  value = world * B * T * args.steps / dt
+
+  if rank == 0:
+    R, S = CFG2['channels'], CFG2['skip_channels']
+    bytes_layer = 4.0 * B * T * (2 * R + S)          # read x, write x_out, write skip
+    achieved = bytes_layer / (avg_ms.value * 1e-3) / 1e9 if avg_ms.value > 0 else 0.0
+    out = {
+        'metric': 'audio samples/sec (training step, 16 kHz mu-law)',
+        'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: 30-layer (3x10) mu-law-256 WaveNet, 64 residual / 256 skip ch, '
+                               f'head [128,256], batch {B}x{T} per GPU, full train step '
+                               '(fwd+loss+bwd+allreduce+clipnorm-Adam)',
+                   'global_batch': world * B, 'samples_per_utterance': T, 'parallelism': f'dp{world}'},
+        'per_gpu_samples_per_s': value / world,
+        'final_loss': logs['loss'],
+        'roofline': {'bound': 'hbm', 'kernel': 'wn_layer_fwd_kernel (fused residual-block forward)',
+                     'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'algorithmic_bytes_per_launch': bytes_layer, 'avg_launch_ms': avg_ms.value,
+                     'launches_timed': n_l.value},
+    }
+    if not args.no_cpu_baseline and world == 1:
+      out['cpu_baseline'] = cpu_baseline(args.cpu_budget)
+    print(json.dumps(out))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,178 @@
+/* libwn_hip.so -- C-ABI of the MI355X (gfx950) WaveNet training / generation hot path.
+ *
+ * Drop-in boundary for jirsat/wavenets (reference paths relative to /root/reference).  The
+ * reference has no FFI: its boundary is the Keras class surface of src/layers.py
+ * (WaveNetLayer) and src/model.py (WaveNet).  The Python mirror of those classes
+ * (wavenets_amd/layers.py, wavenets_amd/model.py) binds exactly the entry points declared
+ * here through ctypes; each one cites the reference method it replaces.
+ *
+ * Conventions
+ *  - all tensors are device pointers to contiguous fp32 (or int32 where stated) buffers in the
+ *    reference's channels-last layout (B, T, C); Conv1D kernels (k, C_in, C_out), Dense
+ *    kernels (in, out), biases (C_out)                        [src/layers.py:134]
+ *  - parameters / gradients / Adam moments are ONE flat fp32 buffer each, tensors in Keras
+ *    creation order (causal; per block: dilated stack, conv1, conv_skip, conv_cond; final
+ *    convs; mapping Dense stack) -- wn_plan_tensor_info() enumerates them
+ *  - no function allocates or frees caller-visible memory: outputs, saved activations and
+ *    scratch live in a caller-provided workspace of wn_plan_workspace_floats() floats
+ *  - every launch is asynchronous on the given hipStream_t (passed as void*); no host sync
+ *  - return value: 0 = ok, <0 = WN_E_* ; message via wn_last_error_string() (thread-local)
+ */
+#ifndef WN_HIP_H
+#define WN_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_OK 0
+#define WN_E_INVALID (-1)      /* bad argument (the Python layer raises ValueError) */
+#define WN_E_UNSUPPORTED (-2)  /* shape / option outside what the kernels cover */
+#define WN_E_HIP (-3)          /* HIP runtime error */
+
+/* activation ids (Keras activation strings used by the reference configs, train.py:35,38) */
+#define WN_ACT_LINEAR 0
+#define WN_ACT_RELU 1
+#define WN_ACT_LEAKY_RELU 2
+#define WN_ACT_TANH 3
+#define WN_ACT_SIGMOID 4
+#define WN_ACT_ELU 5
+
+/* output head / sampling_function (src/model.py:65-69) */
+#define WN_HEAD_CATEGORICAL 0
+#define WN_HEAD_LOGISTIC 1
+#define WN_HEAD_GAUSSIAN 2
+
+#define WN_MAX_FINAL 8
+#define WN_MAX_MAPPING 8
+
+/* Mirror of the WaveNet constructor keywords, src/model.py:14-34 */
+typedef struct wn_config {
+  int32_t kernel_size;
+  int32_t channels;
+  int32_t blocks;
+  int32_t layers_per_block;
+  int32_t activation;           /* WN_ACT_* for non-gated convs and the head */
+  int32_t dilation_bound;
+  int32_t num_mixtures;         /* 0 = None */
+  int32_t head;                 /* WN_HEAD_* */
+  int32_t bits;
+  int32_t skip_channels;        /* 0 = None */
+  int32_t dilation_channels;    /* 0 = None (-> channels, src/layers.py:49-50) */
+  int32_t use_residual;
+  int32_t use_skip;
+  int32_t n_final;              /* len(final_layers_channels) */
+  int32_t final_channels[WN_MAX_FINAL];
+  int32_t cond_inputs;          /* 0 = conditioning None; else width of the raw global condition */
+  int32_t n_mapping;            /* len(mapping_layers) */
+  int32_t mapping_channels[WN_MAX_MAPPING];
+  int32_t mapping_activation;
+  float l2_reg_factor;
+} wn_config;
+
+typedef struct wn_plan wn_plan;
+
+const char* wn_last_error_string(void);
+
+/* ---- plan: immutable launch metadata (WaveNet.__init__ + build, src/model.py:14-211) ---- */
+wn_plan* wn_plan_create(const wn_config* cfg);          /* NULL on error */
+void wn_plan_destroy(wn_plan* p);
+int64_t wn_plan_param_count(const wn_plan* p);
+int32_t wn_plan_num_tensors(const wn_plan* p);
+/* tensor idx in Keras creation order: flat offset, element count, rank, shape[3] */
+int wn_plan_tensor_info(const wn_plan* p, int32_t idx, int64_t* offset, int64_t* len,
+                        int32_t* ndim, int64_t* shape3, int32_t* is_kernel);
+int32_t wn_plan_receptive_field(const wn_plan* p);      /* src/model.py:122 */
+int32_t wn_plan_out_channels(const wn_plan* p);
+int32_t wn_plan_dilation(const wn_plan* p, int32_t conv_index);   /* src/model.py:79-81 */
+/* workspace size in floats for a (B, T) call; training != 0 keeps activations for backward */
+int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t T, int32_t training);
+
+/* ---- measurement hook (bench.py): HIP events around each residual-block forward launch on
+ * the caller's stream; wn_prof_read returns the average per-launch time after a stream sync.
+ * Not part of the reference surface. */
+int wn_prof_enable(wn_plan* p, int32_t max_launches);
+int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
+
+/* ---- WaveNet.call, src/model.py:213-239 ----
+ * x (B,T,1); cond (B, cond_inputs) or NULL; out (B,T,C_out): probabilities (categorical) or
+ * linear mixture parameters; logits_out optional (B,T,C_out) pre-softmax. */
+int wn_forward(wn_plan* p, const float* params, const float* x, const float* cond, int32_t B,
+               int32_t T, float* out, float* logits_out, float* workspace, int64_t ws_floats,
+               void* stream);
+
+/* ---- gradient half of WaveNet.train_step, src/model.py:319-335 ----
+ * x_full (B,T+1,1): inputs = x[:, :-1], targets = prepare_target(x[:, 1:]).
+ * loss = sum_{b,t} l / global_batch (+ l2 * sum W^2 / n_replicas).  grads receives
+ * d(loss)/d(params) for THIS replica's rows (to be SUM-all-reduced by the caller).
+ * loss_out: 2 device floats {loss, reg_loss}.  pred_out optional (B,T,C_out). */
+int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_full, const float* cond,
+                     int32_t B, int32_t T, int32_t global_batch, int32_t n_replicas, float* grads,
+                     float* loss_out, float* pred_out, float* workspace, int64_t ws_floats,
+                     void* stream);
+
+/* ---- WaveNet.test_step loss, src/model.py:362-381 (forward + loss only) ---- */
+int wn_eval_loss(wn_plan* p, const float* params, const float* x_full, const float* cond,
+                 int32_t B, int32_t T, int32_t global_batch, float* loss_out, float* pred_out,
+                 float* workspace, int64_t ws_floats, void* stream);
+
+/* ---- optimizer.apply_gradients with Adam(lr, clipnorm), train.py:225-226, model.py:336 ----
+ * Keras Adam: alpha = lr*sqrt(1-b2^t)/(1-b1^t); p -= alpha*m/(sqrt(v)+eps); per-tensor
+ * tf.clip_by_norm when clipnorm > 0.  step is 1-based.  scratch: >= num_tensors floats. */
+int wn_adam_step(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,
+                 float lr, float beta1, float beta2, float eps, float clipnorm, float* scratch,
+                 void* stream);
+
+/* ---- WaveNet.generate / _generation, src/model.py:241-307 (intended semantics) ----
+ * window (B,RF,1) initial samples; out (B,length,1).  deterministic != 0: argmax / mode
+ * sampling; else Philox draws keyed by seed.  queued != 0 uses per-layer ring buffers
+ * (result-identical to the sliding window; the reference's README.md:16 TODO). */
+int wn_generate(wn_plan* p, const float* params, const float* window, const float* cond, int32_t B,
+                int32_t length, int32_t deterministic, int32_t queued, uint64_t seed, float* out,
+                float* workspace, int64_t ws_floats, void* stream);
+int64_t wn_generate_workspace_floats(const wn_plan* p, int32_t B, int32_t queued);
+
+/* ---- WaveNetLayer.call, src/layers.py:178-224, standalone block ----
+ * weights in Keras layout: dil_kernels = layers_in_block kernels concatenated
+ * [(k,Cin_i,Cout_i)...], dil_biases likewise; conv1 (D,R); conv_skip (D,S) or NULL;
+ * conv_cond (Cc,2D) or NULL with cond (B,T,Cc).  dilations[depth].
+ * saved: caller buffer of wn_layer_saved_floats() floats kept for wn_layer_bwd (or NULL). */
+typedef struct wn_layer_desc {
+  int32_t kernel_size, channels, dilation_channels, skip_channels /*0 = None*/;
+  int32_t depth;                 /* len(dilation_rate) */
+  int32_t dilations[16];
+  int32_t activation, residual, cond_channels /*0 = no condition*/;
+  int32_t in_channels;           /* channels of the input tensor */
+} wn_layer_desc;
+int64_t wn_layer_saved_floats(const wn_layer_desc* d, int32_t B, int32_t T);
+int64_t wn_layer_workspace_floats(const wn_layer_desc* d, int32_t B, int32_t T);
+int wn_layer_fwd(const wn_layer_desc* d, const float* params, const float* x, const float* cond,
+                 int32_t B, int32_t T, float* x_out, float* skip_out, float* saved,
+                 float* workspace, void* stream);
+int wn_layer_bwd(const wn_layer_desc* d, const float* params, const float* x, const float* cond,
+                 const float* saved, const float* g_x_out, const float* g_skip, int32_t B, int32_t T,
+                 float* g_x, float* g_cond, float* g_params, float* workspace, void* stream);
+int64_t wn_layer_param_count(const wn_layer_desc* d);
+
+/* ---- elementwise pieces of the boundary ---- */
+/* prepare_target = Discretization (tf Bucketize), src/model.py:151-153: bit-exact indices */
+int wn_quantize(const float* x, int32_t* idx, int64_t n, int32_t bits, void* stream);
+/* index -> left bin edge, src/model.py:411,418 */
+int wn_dequantize(const int32_t* idx, float* x, int64_t n, int32_t bits, void* stream);
+/* mu-law companding src/utils.py:34-35 and its inverse src/callbacks.py:126-131 */
+int wn_mulaw(const float* x, float* y, int64_t n, void* stream);
+int wn_inv_mulaw(const float* y, float* x, int64_t n, void* stream);
+/* WaveNet.loss_fn(target, pred), src/model.py:505-551: per-(b,t) loss, rows = B*T.
+ * categorical: target int32 indices, pred probabilities; mixtures: target fp32 values. */
+int wn_loss_fn(int32_t head, const void* target, const float* pred, int64_t rows, int32_t C,
+               int32_t num_mixtures, int32_t bits, float* loss_rows, void* stream);
+/* WaveNet.sample_waveform(pred, deterministic), src/model.py:393-503: (rows,C) -> (rows) */
+int wn_sample_waveform(int32_t head, const float* pred, int64_t rows, int32_t C,
+                       int32_t num_mixtures, int32_t bits, int32_t deterministic, uint64_t seed,
+                       uint64_t offset, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WN_HIP_H */

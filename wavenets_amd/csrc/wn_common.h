@@ -1,0 +1,90 @@
+// Common device-side helpers for the gfx950 WaveNet kernels.
+//
+// Orientation used by every contraction kernel ("time on lanes"):
+//   D[i = channel][j = time] += A[i][k] * B[k][j]     v_mfma_f32_32x32x2_f32 (exact fp32)
+//   A operand  (weights)      lane l holds A[i = l&31][k = l>>5]
+//   B operand  (activations)  lane l holds B[k = l>>5][j = l&31]
+//   C/D tile   lane l, reg r  holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// A wave therefore owns 32 consecutive time steps (one per lane pair) and ALL output
+// channels of them; a D tile's registers are, unchanged, the B operand of the next
+// contraction over its channel index (k order 8q + 4h + e, see wn_frag_index), so the
+// dilated conv -> gate -> 1x1 chain never leaves registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wn_hip.h"   // WN_OK / WN_E_* / WN_ACT_* / WN_HEAD_* constants
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum WnEpilogue : int {
+  WN_EPI_PLAIN = 0,      // y = act(acc + bias + rowbias + addc)
+  WN_EPI_DACT = 1,       // y = (acc + addc) * act'(saved y)        (backward data)
+  WN_EPI_GATE_BWD = 2,   // acc is dL/dz; y[:, :D] = dL/du_f, y[:, D:] = dL/du_g from saved (a, g)
+};
+
+__device__ __forceinline__ f32x16 wn_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of a 32x32 D tile held by register r of a lane in half h = lane >> 5
+__device__ __forceinline__ int wn_drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float wn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wn_act(float x, int act) {
+  switch (act) {
+    case WN_ACT_RELU: return x > 0.f ? x : 0.f;
+    case WN_ACT_LEAKY_RELU: return x >= 0.f ? x : 0.2f * x;
+    case WN_ACT_TANH: return tanhf(x);
+    case WN_ACT_SIGMOID: return wn_sigmoid(x);
+    case WN_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    default: return x;
+  }
+}
+
+// derivative of the activation expressed through its OUTPUT y (all supported activations
+// are invertible enough for this: sign(y) == sign(x) for relu / leaky / elu)
+__device__ __forceinline__ float wn_dact_from_y(float y, int act) {
+  switch (act) {
+    case WN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case WN_ACT_LEAKY_RELU: return y >= 0.f ? 1.f : 0.2f;
+    case WN_ACT_TANH: return 1.f - y * y;
+    case WN_ACT_SIGMOID: return y * (1.f - y);
+    case WN_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+    default: return 1.f;
+  }
+}
+
+// Fragment-major weight image.  For a matrix A[I][KK] (I output rows, KK contraction) the
+// image is a sequence of 1 KiB blocks, one per (k-quad q = kk/8, row tile j = i/32):
+//   img[((q * JT + j) * 64 + lane) * 4 + e] = A[32 j + (lane & 31)][8 q + 4 (lane >> 5) + e]
+// so that one coalesced 16-byte-per-lane load gives a lane its A operand for 4 MFMA steps.
+__host__ __device__ __forceinline__ size_t wn_frag_floats(int I, int KK) {
+  return (size_t)((KK + 7) / 8) * ((I + 31) / 32) * 256;
+}
+
+// compile-time loop: the body receives std::integral_constant<int, I>, so register arrays
+// indexed by it can never be demoted to private memory by a failed unroll
+#ifdef __cplusplus
+#include <type_traits>
+template <int N, class F>
+__device__ __forceinline__ void wn_static_for(F&& f) {
+  if constexpr (N > 0) {
+    wn_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+#endif
+
+#define WN_HIP_CHECK(expr)                                   \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) {                                  \
+      wn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return WN_E_HIP;                                       \
+    }                                                        \
+  } while (0)
+
+void wn_set_error(const char* fmt, ...);

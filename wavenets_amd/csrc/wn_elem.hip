@@ -1,0 +1,608 @@
+// Elementwise, loss, sampling and reduction kernels of the WaveNet hot path (gfx950).
+// References: quantiser src/model.py:151-153; mu-law src/utils.py:34-35; inverse
+// src/callbacks.py:126-131; losses src/model.py:505-551; samplers src/model.py:393-503.
+#include "wn_kernels.h"
+
+#define WN_KERAS_EPS 1e-7f
+
+static inline int wn_blocks(int64_t n, int per = 256, int cap = 4096) {
+  int64_t b = (n + per - 1) / per;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void wn_add_kernel(const float* a, const float* b, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+int wn_launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_add_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, a, b, out, n);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+__global__ void wn_fill_kernel(float* p, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+int wn_launch_fill(float* p, float v, int64_t n, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_fill_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, p, v, n);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// out[b][c] = sum_t g[b][t][c]
+__global__ void wn_colsum_kernel(const float* g, int T, int C, float* out) {
+  __shared__ double part[256];
+  const int b = blockIdx.x;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int p = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (c < C)
+    for (int t = p; t < T; t += 4) acc += (double)g[((int64_t)b * T + t) * C + c];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (p == 0 && c < C)
+    out[(int64_t)b * C + c] = (float)(part[threadIdx.x] + part[threadIdx.x + 64] +
+                                      part[threadIdx.x + 128] + part[threadIdx.x + 192]);
+}
+int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(wn_colsum_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, s, g, T, C, out);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// quantiser: index = #{ j in 1..2^bits-1 : edge_j <= x },  edge_j = -1 + j * 2^(1-bits) (exact in
+// fp32).  Candidate from arithmetic, then corrected against the exact edges so that the result is
+// the upper-bound search of tf Bucketize bit for bit.
+__device__ __forceinline__ int wn_quantize_one(float x, int bits) {
+  const int nmax = (1 << bits) - 1;
+  const double step = ldexp(1.0, 1 - bits);
+  double f = floor(((double)x + 1.0) / step);
+  int idx = f < 0.0 ? 0 : (f > (double)nmax ? nmax : (int)f);
+  while (idx > 0 && (float)(-1.0 + idx * step) > x) --idx;
+  while (idx < nmax && (float)(-1.0 + (idx + 1) * step) <= x) ++idx;
+  return idx;
+}
+__global__ void wn_quantize_kernel(const float* x, int32_t* idx, int64_t n, int bits) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    idx[i] = wn_quantize_one(x[i], bits);
+}
+int wn_launch_quantize(const float* x, int32_t* idx, int64_t n, int bits, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  if (bits < 1 || bits > 16) { wn_set_error("quantize: bits %d unsupported", bits); return WN_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(wn_quantize_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, x, idx, n, bits);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+__global__ void wn_dequantize_kernel(const int32_t* idx, float* x, int64_t n, float inv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = (float)idx[i] * inv - 1.0f;       // i / 2^(bits-1) - 1  (src/model.py:411,418)
+}
+int wn_launch_dequantize(const int32_t* idx, float* x, int64_t n, int bits, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_dequantize_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, idx, x, n,
+                     1.0f / (float)(1 << (bits - 1)));
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+__global__ void wn_mulaw_kernel(const float* x, float* y, int64_t n) {
+  const float inv = 1.0f / logf(256.0f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const float sgn = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+    y[i] = sgn * (logf(1.0f + 255.0f * fabsf(v)) * inv);
+  }
+}
+int wn_launch_mulaw(const float* x, float* y, int64_t n, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_mulaw_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, x, y, n);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+__global__ void wn_inv_mulaw_kernel(const float* y, float* x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = y[i];
+    const float sgn = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+    x[i] = sgn * (powf(256.0f, fabsf(v)) - 1.0f) / 255.0f;
+  }
+}
+int wn_launch_inv_mulaw(const float* y, float* x, int64_t n, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_inv_mulaw_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, y, x, n);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave-per-row helpers
+__device__ __forceinline__ float wn_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void wn_softmax_kernel(const float* logits, float* probs,
+                                                         int64_t rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* l = logits + row * C;
+  float m = -INFINITY;
+  for (int j = lane; j < C; j += 64) m = fmaxf(m, l[j]);
+  m = wn_wave_max(m);
+  float z = 0.f;
+  for (int j = lane; j < C; j += 64) z += expf(l[j] - m);
+  z = wn_wave_sum(z);
+  const float inv = 1.0f / z;
+  for (int j = lane; j < C; j += 64) probs[row * C + j] = expf(l[j] - m) * inv;
+}
+int wn_launch_softmax(const float* logits, float* probs, int64_t rows, int C, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
+                     probs, rows, C);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// Keras sparse_categorical_crossentropy(target, softmax(logits)), from_logits=False:
+//   q = softmax(logits); p = clip(q, eps, 1-eps); loss = -(log p_t - log sum_j p_j)
+// and its gradient w.r.t. the logits (clip passes gradient where eps <= q <= 1-eps).
+__global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, const int32_t* target,
+                                                          int64_t rows, int C, float gscale,
+                                                          float* loss_rows, float* g_logits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* l = logits + row * C;
+  float m = -INFINITY;
+  for (int j = lane; j < C; j += 64) m = fmaxf(m, l[j]);
+  m = wn_wave_max(m);
+  float z = 0.f;
+  for (int j = lane; j < C; j += 64) z += expf(l[j] - m);
+  z = wn_wave_sum(z);
+  const float inv = 1.0f / z;
+  float S = 0.f, A = 0.f;
+  for (int j = lane; j < C; j += 64) {
+    const float q = expf(l[j] - m) * inv;
+    const float p = fminf(fmaxf(q, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+    S += p;
+    if (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) A += q;
+  }
+  S = wn_wave_sum(S);
+  A = wn_wave_sum(A);
+  int tgt = target[row];
+  tgt = tgt < 0 ? 0 : (tgt >= C ? C - 1 : tgt);
+  const float qt = expf(l[tgt] - m) * inv;
+  const float pt = fminf(fmaxf(qt, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+  const float ct = (qt >= WN_KERAS_EPS && qt <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+  if (lane == 0) loss_rows[row] = -(logf(pt) - logf(S));
+  if (g_logits) {
+    const float invS = 1.0f / S;
+    const float dot = A * invS - ct * qt / pt;     // sum_j g_j q_j
+    for (int j = lane; j < C; j += 64) {
+      const float q = expf(l[j] - m) * inv;
+      const float c = (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+      float g = c * invS;
+      if (j == tgt) g -= ct / pt;
+      g_logits[row * C + j] = gscale * q * (g - dot);
+    }
+  }
+}
+int wn_launch_cat_loss(const float* logits, const int32_t* target, int64_t rows, int C,
+                       float gscale, float* loss_rows, float* g_logits, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_cat_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
+                     target, rows, C, gscale, loss_rows, g_logits);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+__global__ __launch_bounds__(256) void wn_cat_loss_probs_kernel(const float* probs,
+                                                                const int32_t* target, int64_t rows,
+                                                                int C, float* loss_rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* q = probs + row * C;
+  float S = 0.f;
+  for (int j = lane; j < C; j += 64) S += fminf(fmaxf(q[j], WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+  S = wn_wave_sum(S);
+  int tgt = target[row];
+  tgt = tgt < 0 ? 0 : (tgt >= C ? C - 1 : tgt);
+  const float pt = fminf(fmaxf(q[tgt], WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+  if (lane == 0) loss_rows[row] = -(logf(pt) - logf(S));
+}
+int wn_launch_cat_loss_probs(const float* probs, const int32_t* target, int64_t rows, int C,
+                             float* loss_rows, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_cat_loss_probs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                     probs, target, rows, C, loss_rows);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// mixture losses, one thread per (b,t) row; M <= 32
+#define WN_MAXMIX 32
+__global__ void wn_mix_loss_kernel(const float* pred, const float* y, int64_t rows, int M, int bits,
+                                   int kind, float gscale, float* loss_rows, float* g_pred) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float* p = pred + row * 3 * M;
+  const float yy = y[row];
+  float w[WN_MAXMIX], comp[WN_MAXMIX];
+  float wm = -INFINITY;
+  for (int k = 0; k < M; ++k) wm = fmaxf(wm, p[k]);
+  float wz = 0.f;
+  for (int k = 0; k < M; ++k) { w[k] = expf(p[k] - wm); wz += w[k]; }
+  const float winv = 1.0f / wz;
+  const float halfbit = 0.5f / (float)(1 << bits);                       // src/model.py:538
+  const float sqrt2pi = sqrtf(2.0f * 3.14159265359f);                    // src/model.py:9
+  float lik = 0.f;
+  for (int k = 0; k < M; ++k) {
+    w[k] *= winv;
+    const float mu = p[M + k];
+    const float ls = fmaxf(p[2 * M + k], -7.0f);
+    if (kind == 1) {
+      const float inv = expf(-ls);
+      comp[k] = wn_sigmoid((yy - mu + halfbit) * inv) - wn_sigmoid((yy - mu - halfbit) * inv);
+    } else {
+      const float sc = expf(ls);
+      const float xx = fminf((yy - mu) / sc, 1e8f);
+      comp[k] = expf(-0.5f * xx * xx) / (sc * sqrt2pi);
+    }
+    lik += w[k] * comp[k];
+  }
+  loss_rows[row] = -logf(lik);
+  if (!g_pred) return;
+  float* g = g_pred + row * 3 * M;
+  const float dl = -gscale / lik;                                        // dL/dlik
+  for (int k = 0; k < M; ++k) {
+    const float mu = p[M + k];
+    const float lsr = p[2 * M + k];
+    const float ls = fmaxf(lsr, -7.0f);
+    const float lsmask = lsr >= -7.0f ? 1.f : 0.f;
+    g[k] = dl * (w[k] * comp[k] - w[k] * lik);
+    if (kind == 1) {
+      const float inv = expf(-ls);
+      const float a = (yy - mu + halfbit) * inv, b = (yy - mu - halfbit) * inv;
+      const float sa = wn_sigmoid(a), sb = wn_sigmoid(b);
+      const float da = sa * (1.f - sa), db = sb * (1.f - sb);
+      g[M + k] = dl * (-w[k] * inv * (da - db));
+      g[2 * M + k] = dl * lsmask * (-w[k] * (a * da - b * db));
+    } else {
+      const float sc = expf(ls);
+      const float xr = (yy - mu) / sc;
+      const float xx = fminf(xr, 1e8f);
+      const float xmask = xr <= 1e8f ? 1.f : 0.f;
+      const float pdf = comp[k];
+      // d pdf/d mu = pdf * xx / sc ; d pdf/d ls = pdf * (xx^2 - 1)
+      g[M + k] = dl * w[k] * pdf * xx / sc * xmask;
+      g[2 * M + k] = dl * lsmask * w[k] * pdf * (xx * xx * xmask - 1.f);
+    }
+  }
+}
+int wn_launch_mix_loss(const float* pred, const float* y, int64_t rows, int M, int bits, int kind,
+                       float gscale, float* loss_rows, float* g_pred, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  if (M < 1 || M > WN_MAXMIX) { wn_set_error("mix_loss: num_mixtures %d unsupported (max %d)", M, WN_MAXMIX); return WN_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(wn_mix_loss_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, pred,
+                     y, rows, M, bits, kind, gscale, loss_rows, g_pred);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// deterministic two-stage sum (double accumulation), out[0] = scale * sum(v)
+__global__ void wn_sum_stage1(const float* v, int64_t n, double* scratch) {
+  __shared__ double sm[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    acc += (double)v[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scratch[blockIdx.x] = sm[0];
+}
+__global__ void wn_sum_stage2(const double* scratch, int nb, float scale, float* out) {
+  __shared__ double sm[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += scratch[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(sm[0] * (double)scale);
+}
+// scratch: >= 1024 doubles (8 KiB)
+int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scratch, hipStream_t s) {
+  int nb = wn_blocks(n, 256, 1024);
+  hipLaunchKernelGGL(wn_sum_stage1, dim3(nb), dim3(256), 0, s, v, n, reinterpret_cast<double*>(scratch));
+  hipLaunchKernelGGL(wn_sum_stage2, dim3(1), dim3(256), 0, s, reinterpret_cast<const double*>(scratch), nb, scale, out);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// samplers
+__global__ __launch_bounds__(256) void wn_sample_det_cat_kernel(const float* pred, int64_t rows, int C,
+                                                                float inv, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = pred + row * C;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < C; j += 64) {
+    const float v = p[j];
+    if (v > best) { best = v; bi = j; }          // strictly greater keeps the first maximum
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) out[row] = (float)bi * inv - 1.0f;
+}
+__global__ void wn_sample_det_mix_kernel(const float* pred, int64_t rows, int M, float* out) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float* p = pred + row * 3 * M;
+  int bi = 0;
+  float best = p[0];
+  for (int k = 1; k < M; ++k) if (p[k] > best) { best = p[k]; bi = k; }
+  out[row] = fminf(fmaxf(p[M + bi], -1.0f), 1.0f);
+}
+int wn_launch_sample_det(const float* pred, int64_t rows, int C, int M, int bits, float* out,
+                         hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  if (M <= 0) {
+    hipLaunchKernelGGL(wn_sample_det_cat_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                       pred, rows, C, 1.0f / (float)(1 << (bits - 1)), out);
+  } else {
+    hipLaunchKernelGGL(wn_sample_det_mix_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       s, pred, rows, M, out);
+  }
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (row, offset), key = seed
+__device__ __forceinline__ void wn_philox(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key, uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float wn_u01(uint32_t r) {   // (0,1), 24-bit
+  return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void wn_sample_rand_cat_kernel(const float* pred, int64_t rows, int C,
+                                                                 float inv, uint64_t seed, uint64_t offset,
+                                                                 float* out) {
+  // inverse-CDF categorical draw from the (unnormalised) probabilities of one row per wave
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = pred + row * C;
+  const int per = (C + 63) / 64;               // contiguous chunk per lane
+  const int j0 = lane * per;
+  float loc = 0.f;
+  for (int j = j0; j < min(C, j0 + per); ++j) loc += fmaxf(p[j], 0.f);
+  float incl = loc;                            // inclusive scan over lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  const float total = __shfl(incl, 63);
+  uint32_t r[4];
+  wn_philox((uint64_t)row, offset, seed, r);
+  const float target = wn_u01(r[0]) * total;
+  const unsigned long long hit = __ballot(incl > target);
+  int sel_lane = hit ? __builtin_ctzll(hit) : 63;
+  int result = C - 1;
+  if (lane == sel_lane) {
+    float run = incl - loc;
+    result = min(C, j0 + per) - 1;
+    for (int j = j0; j < min(C, j0 + per); ++j) {
+      run += fmaxf(p[j], 0.f);
+      if (run > target) { result = j; break; }
+    }
+    out[row] = (float)result * inv - 1.0f;
+  }
+}
+__global__ void wn_sample_rand_mix_kernel(const float* pred, int64_t rows, int M, int kind, uint64_t seed,
+                                          uint64_t offset, float* out) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float* p = pred + row * 3 * M;
+  uint32_t r[4];
+  wn_philox((uint64_t)row, offset, seed, r);
+  float wm = -INFINITY;
+  for (int k = 0; k < M; ++k) wm = fmaxf(wm, p[k]);
+  float wz = 0.f;
+  for (int k = 0; k < M; ++k) wz += expf(p[k] - wm);
+  const float target = wn_u01(r[0]) * wz;
+  int sel = M - 1;
+  float run = 0.f;
+  for (int k = 0; k < M; ++k) { run += expf(p[k] - wm); if (run > target) { sel = k; break; } }
+  const float mu = p[M + sel], sc = expf(p[2 * M + sel]);
+  float v;
+  if (kind == 1) {                       // logistic: mu + s (ln z - ln(1-z))     src/model.py:463-483
+    const float zz = wn_u01(r[1]);
+    v = mu + sc * (logf(zz) - logf(1.0f - zz));
+  } else {                               // gaussian: mu + s n                   src/model.py:423-443
+    const float u1 = wn_u01(r[1]), u2 = wn_u01(r[2]);
+    v = mu + sc * sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+  out[row] = fminf(fmaxf(v, -1.0f), 1.0f);
+}
+int wn_launch_sample_rand(const float* pred, int64_t rows, int C, int M, int bits, int kind,
+                          uint64_t seed, uint64_t offset, float* out, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  if (M <= 0) {
+    hipLaunchKernelGGL(wn_sample_rand_cat_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                       pred, rows, C, 1.0f / (float)(1 << (bits - 1)), seed, offset, out);
+  } else {
+    hipLaunchKernelGGL(wn_sample_rand_mix_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       s, pred, rows, M, kind, seed, offset, out);
+  }
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// optimizer: per-tensor clipnorm + Keras Adam  (train.py:225-226, src/model.py:336)
+__global__ void wn_sumsq_kernel(const float* g, const WnTensorDesc* table, float* norms2) {
+  __shared__ double sm[256];
+  const WnTensorDesc d = table[blockIdx.x];
+  const float* p = g + d.off;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < d.len; i += blockDim.x) acc += (double)p[i] * (double)p[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) norms2[blockIdx.x] = (float)sm[0];
+}
+int wn_launch_sumsq(const float* g, const WnTensorDesc* d_table, int n, float* norms2, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_sumsq_kernel, dim3(n), dim3(256), 0, s, g, d_table, norms2);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+__global__ void wn_adam_kernel(float* p, const float* g, float* m, float* v, const WnTensorDesc* table,
+                               const float* norms2, float clipnorm, float alpha, float beta1,
+                               float beta2, float eps) {
+  const WnTensorDesc d = table[blockIdx.y];
+  float scale = 1.0f;
+  if (clipnorm > 0.f) {
+    const float nrm = sqrtf(norms2[blockIdx.y]);
+    scale = clipnorm / fmaxf(nrm, clipnorm);     // tf.clip_by_norm
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = d.off + i;
+    const float gi = g[k] * scale;
+    const float mi = m[k] + (gi - m[k]) * (1.0f - beta1);
+    const float vi = v[k] + (gi * gi - v[k]) * (1.0f - beta2);
+    m[k] = mi;
+    v[k] = vi;
+    p[k] = p[k] - alpha * mi / (sqrtf(vi) + eps);
+  }
+}
+int wn_launch_adam(float* p, const float* g, float* m, float* v, const WnTensorDesc* d_table, int n,
+                   const float* norms2, float clipnorm, float alpha, float beta1, float beta2,
+                   float eps, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_adam_kernel, dim3(32, n), dim3(256), 0, s, p, g, m, v, d_table, norms2,
+                     clipnorm, alpha, beta1, beta2, eps);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gate of the composed (unfused) block path: u (rows, 2D) -> a = tanh(u[:, :D]), g = sigmoid(u[:, D:]),
+// z = a * g   (src/layers.py:208-210)
+__global__ void wn_gate_kernel(const float* u, int64_t rows, int D, float* ag, float* z, int ldz) {
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D;
+    const int c = (int)(i % D);
+    const float a = tanhf(u[r * 2 * D + c]);
+    const float g = wn_sigmoid(u[r * 2 * D + D + c]);
+    if (ag) { ag[r * 2 * D + c] = a; ag[r * 2 * D + D + c] = g; }
+    if (z) z[r * ldz + c] = a * g;
+  }
+}
+int wn_launch_gate(const float* u, int64_t rows, int D, float* ag, float* z, int ldz, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_gate_kernel, dim3(wn_blocks(rows * D)), dim3(256), 0, s, u, rows, D, ag, z, ldz);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// out[b][n] = sum_sp slab[b][sp][n]
+__global__ void wn_batch_reduce_kernel(const float* slab, int splits, int N, float* out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / N;
+  const int n = (int)(i % N);
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += slab[(b * splits + s) * N + n];
+  out[i] = acc;
+}
+int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)B * N;
+  if (total <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_batch_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                     slab, splits, N, out, total);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// y[off + i] += coef * x[off + i] over the tensors of a table (L2 regulariser gradient)
+__global__ void wn_axpy_table_kernel(float* y, const float* x, const WnTensorDesc* table, float coef) {
+  const WnTensorDesc d = table[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.len;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[d.off + i] += coef * x[d.off + i];
+}
+int wn_launch_axpy_table(float* y, const float* x, const WnTensorDesc* d_table, int n, float coef,
+                         hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_axpy_table_kernel, dim3(16, n), dim3(256), 0, s, y, x, d_table, coef);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// out = g * act'(y)   (y = saved activation output)
+__global__ void wn_dact_mul_kernel(const float* g, const float* y, float* out, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = g[i] * wn_dact_from_y(y[i], act);
+}
+int wn_launch_dact_mul(const float* g, const float* y, float* out, int64_t n, int act, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_dact_mul_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, g, y, out, n, act);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

@@ -1,0 +1,132 @@
+// Internal launcher interface between the kernel translation units and the plan/C-ABI layer.
+#pragma once
+#include "wn_common.h"
+
+// ---------------------------------------------------------------- weight preparation
+// One descriptor = one dense matrix copied into a fragment-major image (wn_common.h).
+// Offsets are in floats relative to the base pointers given at launch, so that a table
+// built once at plan creation works with whatever buffers the caller passes per call.
+struct WnPrepDesc {
+  int64_t src_off;   // into params
+  int64_t dst_off;   // into workspace
+  int32_t I;         // image rows (output channels of the contraction)
+  int32_t KK;        // contraction length
+  int32_t ld;        // leading dimension of the source matrix
+  int32_t transpose; // 0: A[i][kk] = src[i*ld + kk]   1: A[i][kk] = src[kk*ld + i]
+  int32_t q_off;     // first k-quad of this piece inside a larger concatenated image
+  int32_t j_off;     // first row tile of this piece inside a larger stacked image
+  int32_t JT;        // row tiles of the whole image
+  int32_t pad_;
+};
+int wn_launch_prep_table(const WnPrepDesc* d_table, int n, const float* params, float* ws,
+                         hipStream_t s);
+int wn_launch_prep_one(WnPrepDesc d, const float* params, float* ws, hipStream_t s);
+// out[i] = sum_j src[offs[j] + i]   (sum of N bias vectors; offsets by value, N <= 64)
+struct WnVecSumArgs { const float* base; int64_t off0; int64_t stride; int32_t count; int32_t len; float* out; };
+int wn_launch_vecsum(WnVecSumArgs a, hipStream_t s);
+
+// ---------------------------------------------------------------- rows GEMM
+#define WN_MAXSEG 4
+struct WnSeg {
+  const float* x;     // [B*T][ldx] activations, channels contiguous
+  const float* frag;  // fragment-major weight image of this K segment (JTtot row tiles)
+  int32_t ldx;
+  int32_t K;          // valid channels of this segment
+  int32_t shift;      // output row t contracts x row t - shift (zero outside [0,T))
+  int32_t vec;        // 1: rows are 16-byte aligned and K % 4 == 0 -> vector loads
+};
+struct WnGemmArgs {
+  WnSeg seg[WN_MAXSEG];
+  int32_t nseg;
+  int32_t B, T;
+  int32_t N;          // valid output channels
+  int32_t JTtot;      // row tiles of the weight images
+  const float* bias;      // [N] or null
+  const float* rowbias;   // [B][ld_rowbias] or null (per-utterance bias: global conditioning)
+  int32_t ld_rowbias;
+  const float* addc;      // [B*T][ld_addc] or null
+  int32_t ld_addc;
+  int32_t act;
+  int32_t epi;
+  const float* aux;       // WN_EPI_DACT: saved activations; WN_EPI_GATE_BWD: saved (a | g)
+  int32_t ld_aux;
+  float* y;
+  int32_t ldy;
+  int32_t vec_out;        // 1: y/addc/aux rows 16-byte aligned, N % 4 == 0
+};
+int wn_launch_gemm_rows(const WnGemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- weight-gradient GEMM
+struct WnWgradArgs {
+  const float* x; int32_t ldx; int32_t K; int32_t shift;   // dW[k][n] = sum_rows x[t-shift][k] g[t][n]
+  const float* g; int32_t ldg; int32_t N;
+  int32_t B, T;
+  int32_t splits_per_b;
+  float* slab;        // [B*splits_per_b][K][N]
+  float* slab_bias;   // [B*splits_per_b][N] or null
+};
+int wn_wgrad_choose_splits(int B, int T, int K, int N);
+int wn_launch_wgrad(const WnWgradArgs& a, hipStream_t s);
+// out[(k / seg_len) * seg_stride + (k % seg_len) * N + n] (+)= sum_s slab[s][k][n]
+struct WnReduceArgs {
+  const float* slab; int32_t nsplit; int32_t K; int32_t N;
+  float* out; int32_t seg_len; int64_t seg_stride; int32_t accumulate;
+  int32_t replicate; int64_t rep_stride;   // write the same result to `replicate` places
+};
+int wn_launch_reduce(const WnReduceArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- fused residual block forward
+struct WnLayerFwdArgs {
+  const float* x;        // [B*T][R]
+  const float* frag_d;   // KS images (tap-major) of A[2D][R]
+  const float* frag_r;   // image of A[R][D]
+  const float* bias_d;   // [2D]
+  const float* bias_r;   // [R]
+  const float* cb;       // [B][2D] conditioning bias or null
+  float* x_out;          // [B*T][R]
+  float* o_out;          // [B*T][R] pre-residual output (skip when skip_channels is None) or null
+  float* z_out; int32_t ldz;   // gated activations, row stride ldz, or null
+  float* ag_out;         // [B*T][2D] saved tanh | sigmoid, or null
+  const float* res;      // residual source [B*T][R] when it is not the conv input (depth > 1), or null
+  int32_t B, T, R, D, KS, dilation, residual;
+};
+int wn_layer_fwd_supported(int R, int D, int KS);
+int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise / loss / sampling
+int wn_launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
+int wn_launch_fill(float* p, float v, int64_t n, hipStream_t s);
+int wn_launch_dact_mul(const float* g, const float* y, float* out, int64_t n, int act, hipStream_t s);
+int wn_launch_gate(const float* u, int64_t rows, int D, float* ag, float* z, int ldz, hipStream_t s);
+int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s);
+int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, hipStream_t s);
+int wn_launch_quantize(const float* x, int32_t* idx, int64_t n, int bits, hipStream_t s);
+int wn_launch_dequantize(const int32_t* idx, float* x, int64_t n, int bits, hipStream_t s);
+int wn_launch_mulaw(const float* x, float* y, int64_t n, hipStream_t s);
+int wn_launch_inv_mulaw(const float* y, float* x, int64_t n, hipStream_t s);
+int wn_launch_softmax(const float* logits, float* probs, int64_t rows, int C, hipStream_t s);
+// categorical: Keras sparse CE on clipped probabilities; g_logits may be null (loss only)
+int wn_launch_cat_loss(const float* logits, const int32_t* target, int64_t rows, int C,
+                       float gscale, float* loss_rows, float* g_logits, hipStream_t s);
+// from_probs variant used by WaveNet.loss_fn(target, pred) on materialised probabilities
+int wn_launch_cat_loss_probs(const float* probs, const int32_t* target, int64_t rows, int C,
+                             float* loss_rows, hipStream_t s);
+// kind 1 = logistic, 2 = gaussian
+int wn_launch_mix_loss(const float* pred, const float* y, int64_t rows, int M, int bits, int kind,
+                       float gscale, float* loss_rows, float* g_pred, hipStream_t s);
+int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scratch, hipStream_t s);
+// deterministic samplers: categorical argmax -> left bin edge; mixtures -> clipped mean
+int wn_launch_sample_det(const float* pred, int64_t rows, int C, int M, int bits, float* out,
+                         hipStream_t s);
+// stochastic samplers (Philox4x32-10 keyed by seed, counter = row)
+int wn_launch_sample_rand(const float* pred, int64_t rows, int C, int M, int bits, int kind,
+                          uint64_t seed, uint64_t offset, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------- optimizer
+struct WnTensorDesc { int64_t off; int64_t len; };
+int wn_launch_sumsq(const float* g, const WnTensorDesc* d_table, int n, float* norms2, hipStream_t s);
+int wn_launch_axpy_table(float* y, const float* x, const WnTensorDesc* d_table, int n, float coef,
+                         hipStream_t s);
+int wn_launch_adam(float* p, const float* g, float* m, float* v, const WnTensorDesc* d_table, int n,
+                   const float* norms2, float clipnorm, float alpha, float beta1, float beta2,
+                   float eps, hipStream_t s);

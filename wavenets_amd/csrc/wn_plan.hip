@@ -1,0 +1,1343 @@
+// Plan + orchestration of the WaveNet hot path behind the C-ABI of include/wn_hip.h.
+//
+// Host-side only (no kernels here): parameter layout in Keras creation order, the table of
+// fragment-major weight images, workspace carving, and the launch sequences that restate
+//   WaveNet.call          src/model.py:213-239
+//   WaveNet.train_step    src/model.py:309-348 (gradient half)
+//   WaveNetLayer.call     src/layers.py:178-224
+// Nothing here allocates caller-visible memory; the two small device tables a plan owns
+// (prep descriptors, tensor table) are immutable launch metadata uploaded on first use.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/wn_hip.h"
+#include "wn_kernels.h"
+
+namespace {
+
+inline int64_t align64(int64_t v) { return (v + 63) & ~(int64_t)63; }
+inline int ceil32(int v) { return (v + 31) / 32; }
+inline int ceil8(int v) { return (v + 7) / 8 * 8; }
+
+struct TensorInfo {
+  int64_t off, len;
+  int ndim;
+  int64_t shape[3];
+  int is_kernel;
+};
+
+// one convolution / dense: raw parameter offsets plus its two weight images
+struct ConvInfo {
+  int kernel_t = -1, bias_t = -1;   // tensor indices
+  int taps = 1, cin = 0, cout = 0, dil = 1;
+  int64_t fragF = -1;   // taps images of A[cout][cin]  (forward:  A[n][k] = W[tap][k][n])
+  int64_t fragB = -1;   // taps images of A[cin][cout]  (backward: A[k][n] = W[tap][k][n])
+  int64_t fragF_stride = 0, fragB_stride = 0;
+};
+
+struct BlockInfo {
+  std::vector<ConvInfo> dil;
+  ConvInfo conv1, conv_skip, conv_cond;
+  bool has_skip = false, has_cond = false;
+};
+
+}  // namespace
+
+struct wn_plan {
+  wn_config c;
+  int KS, R, D, S, N, LPB, Cout, Sh, Hin, Cc, Dp;
+  std::vector<int> dilations;
+  std::vector<TensorInfo> tensors;
+  int64_t nparams = 0;
+  ConvInfo causal;
+  std::vector<BlockInfo> blocks;
+  std::vector<ConvInfo> finals, mapping;
+  int64_t frag_skipF = -1;     // A[Sh][N*Dp] image of the folded skip sum
+  int64_t frag_floats = 0;
+  std::vector<WnPrepDesc> prep;
+  std::vector<WnTensorDesc> tdesc, kdesc;
+  // device copies (lazy)
+  WnPrepDesc* d_prep = nullptr;
+  WnTensorDesc* d_tdesc = nullptr;
+  WnTensorDesc* d_kdesc = nullptr;
+  bool fused_ok = false;
+  // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
+  std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
+  int prof_used = 0;
+  bool prof_on = false;
+};
+
+namespace {
+
+int add_tensor(wn_plan* p, int ndim, int64_t s0, int64_t s1, int64_t s2, int is_kernel) {
+  TensorInfo t;
+  t.off = p->nparams;
+  t.ndim = ndim;
+  t.shape[0] = s0; t.shape[1] = s1; t.shape[2] = s2;
+  t.len = s0 * (ndim > 1 ? s1 : 1) * (ndim > 2 ? s2 : 1);
+  t.is_kernel = is_kernel;
+  p->nparams += t.len;
+  p->tensors.push_back(t);
+  return (int)p->tensors.size() - 1;
+}
+
+ConvInfo add_conv(wn_plan* p, int taps, int cin, int cout, int dil) {
+  ConvInfo c;
+  c.taps = taps; c.cin = cin; c.cout = cout; c.dil = dil;
+  c.kernel_t = add_tensor(p, 3, taps, cin, cout, 1);
+  c.bias_t = add_tensor(p, 1, cout, 1, 1, 0);
+  return c;
+}
+
+ConvInfo add_dense(wn_plan* p, int cin, int cout) {
+  ConvInfo c;
+  c.taps = 1; c.cin = cin; c.cout = cout; c.dil = 1;
+  c.kernel_t = add_tensor(p, 2, cin, cout, 1, 1);
+  c.bias_t = add_tensor(p, 1, cout, 1, 1, 0);
+  return c;
+}
+
+void add_images(wn_plan* p, ConvInfo& c, bool fwd, bool bwd) {
+  const TensorInfo& k = p->tensors[c.kernel_t];
+  if (fwd) {
+    c.fragF = p->frag_floats;
+    c.fragF_stride = (int64_t)wn_frag_floats(c.cout, c.cin);
+    for (int t = 0; t < c.taps; ++t) {
+      WnPrepDesc d;
+      memset(&d, 0, sizeof(d));
+      d.src_off = k.off + (int64_t)t * c.cin * c.cout;
+      d.dst_off = c.fragF + t * c.fragF_stride;
+      d.I = c.cout; d.KK = c.cin; d.ld = c.cout; d.transpose = 1;
+      d.q_off = 0; d.j_off = 0; d.JT = ceil32(c.cout);
+      p->prep.push_back(d);
+    }
+    p->frag_floats += c.taps * c.fragF_stride;
+  }
+  if (bwd) {
+    c.fragB = p->frag_floats;
+    c.fragB_stride = (int64_t)wn_frag_floats(c.cin, c.cout);
+    for (int t = 0; t < c.taps; ++t) {
+      WnPrepDesc d;
+      memset(&d, 0, sizeof(d));
+      d.src_off = k.off + (int64_t)t * c.cin * c.cout;
+      d.dst_off = c.fragB + t * c.fragB_stride;
+      d.I = c.cin; d.KK = c.cout; d.ld = c.cout; d.transpose = 0;
+      d.q_off = 0; d.j_off = 0; d.JT = ceil32(c.cin);
+      p->prep.push_back(d);
+    }
+    p->frag_floats += c.taps * c.fragB_stride;
+  }
+}
+
+int ensure_device_tables(wn_plan* p) {
+  if (p->d_prep) return WN_OK;
+  WN_HIP_CHECK(hipMalloc((void**)&p->d_prep, p->prep.size() * sizeof(WnPrepDesc)));
+  WN_HIP_CHECK(hipMemcpy(p->d_prep, p->prep.data(), p->prep.size() * sizeof(WnPrepDesc), hipMemcpyHostToDevice));
+  WN_HIP_CHECK(hipMalloc((void**)&p->d_tdesc, p->tdesc.size() * sizeof(WnTensorDesc)));
+  WN_HIP_CHECK(hipMemcpy(p->d_tdesc, p->tdesc.data(), p->tdesc.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+  if (!p->kdesc.empty()) {
+    WN_HIP_CHECK(hipMalloc((void**)&p->d_kdesc, p->kdesc.size() * sizeof(WnTensorDesc)));
+    WN_HIP_CHECK(hipMemcpy(p->d_kdesc, p->kdesc.data(), p->kdesc.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+  }
+  return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------
+struct Carver {
+  int64_t pos = 0;
+  int64_t take(int64_t n) { int64_t o = pos; pos = align64(pos + (n > 0 ? n : 0)); return o; }
+};
+
+struct WsLayout {
+  int64_t frag, bias_sum;
+  std::vector<int64_t> H;               // N+1 block inputs/outputs (training) or 2 (inference)
+  std::vector<std::vector<int64_t>> P;  // per block: outputs of the non-gated convs (depth > 1)
+  int64_t Z;                            // [rows][N*Dp]
+  std::vector<int64_t> AG;              // per block [rows][2D] (training)
+  int64_t U;                            // [rows][2D] scratch of the composed path / g_u
+  int64_t O;                            // [rows][R] pre-residual output scratch
+  int64_t skipsum;                      // [rows][Hin]
+  std::vector<int64_t> HA;              // head activations
+  int64_t logits, probs;
+  int64_t target, loss_rows, yt;
+  int64_t g_a, g_b;                     // head gradient ping-pong [rows][maxC]
+  int64_t g_skipsum;                    // [rows][Hin]
+  int64_t g_h0, g_h1;                   // [rows][max(R,D)]
+  int64_t g_o;                          // [rows][R]
+  int64_t g_p;                          // [rows][D] (depth > 1)
+  int64_t slab, slab_floats;
+  int64_t sum_scratch;
+  std::vector<int64_t> M;               // mapping activations [B][w]
+  int64_t cb;                           // [N][B][2D]
+  int64_t dcb, g_m0, g_m1;
+  int64_t total;
+};
+
+int64_t slab_need(int B, int T, int K, int N) {
+  const int sp = wn_wgrad_choose_splits(B, T, K, N);
+  return (int64_t)B * sp * ((int64_t)K * N + N);
+}
+
+WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
+  WsLayout L;
+  Carver cv;
+  const int64_t rows = (int64_t)B * T;
+  L.frag = cv.take(p->frag_floats);
+  L.bias_sum = cv.take(p->Hin);
+  const int nH = training ? p->N + 1 : 2;
+  const int hc = std::max(p->R, p->D);
+  for (int i = 0; i < nH; ++i) L.H.push_back(cv.take(rows * hc));
+  L.P.resize(p->N);
+  if (p->LPB > 1) {
+    const int nP = training ? p->N : 1;
+    std::vector<std::vector<int64_t>> tmp(nP);
+    for (int b = 0; b < nP; ++b)
+      for (int i = 0; i < p->LPB - 1; ++i) tmp[b].push_back(cv.take(rows * p->D));
+    for (int b = 0; b < p->N; ++b) L.P[b] = tmp[training ? b : 0];
+  }
+  L.Z = cv.take(rows * p->N * p->Dp);
+  if (training) for (int b = 0; b < p->N; ++b) L.AG.push_back(cv.take(rows * 2 * p->D));
+  L.U = cv.take(rows * 2 * p->D);
+  L.O = cv.take(rows * p->R);
+  L.skipsum = cv.take(rows * p->Hin);
+  int maxC = std::max(p->Hin, p->Cout);
+  for (size_t i = 0; i + 1 < p->finals.size(); ++i) {
+    L.HA.push_back(cv.take(rows * p->finals[i].cout));
+    maxC = std::max(maxC, p->finals[i].cout);
+  }
+  L.logits = cv.take(rows * p->Cout);
+  L.probs = cv.take(rows * p->Cout);
+  L.target = cv.take(rows);
+  L.loss_rows = cv.take(rows);
+  L.yt = cv.take(rows);
+  L.sum_scratch = cv.take(2048 + 64);
+  // conditioning
+  if (p->c.cond_inputs > 0) {
+    for (size_t j = 0; j < p->mapping.size(); ++j) L.M.push_back(cv.take((int64_t)B * p->mapping[j].cout));
+    L.cb = cv.take((int64_t)p->N * B * 2 * p->D);
+    L.dcb = cv.take((int64_t)B * 2 * p->D);
+    int mw = std::max(p->Cc, p->c.cond_inputs);
+    for (auto& m : p->mapping) mw = std::max(mw, m.cout);
+    L.g_m0 = cv.take((int64_t)B * mw);
+    L.g_m1 = cv.take((int64_t)B * mw);
+  } else {
+    L.cb = L.dcb = L.g_m0 = L.g_m1 = 0;
+  }
+  if (training) {
+    L.g_a = cv.take(rows * maxC);
+    L.g_b = cv.take(rows * maxC);
+    L.g_skipsum = cv.take(rows * p->Hin);
+    L.g_h0 = cv.take(rows * hc);
+    L.g_h1 = cv.take(rows * hc);
+    L.g_o = cv.take(rows * p->R);
+    L.g_p = cv.take(p->LPB > 1 ? 2 * rows * p->D : 0);
+    int64_t need = 0;
+    need = std::max(need, slab_need(B, T, 1, p->R));
+    for (const BlockInfo& b : p->blocks) {
+      for (const ConvInfo& c : b.dil) need = std::max(need, slab_need(B, T, c.cin, c.cout));
+      need = std::max(need, slab_need(B, T, p->D, p->R));
+      if (b.has_skip) need = std::max(need, slab_need(B, T, p->D, p->S));
+    }
+    for (const ConvInfo& c : p->finals) need = std::max(need, slab_need(B, T, c.cin, c.cout));
+    for (const ConvInfo& c : p->mapping) need = std::max(need, slab_need(1, B, c.cin, c.cout));
+    if (p->c.cond_inputs > 0) need = std::max(need, slab_need(1, B, p->Cc, 2 * p->D));
+    L.slab_floats = need;
+    L.slab = cv.take(need);
+  } else {
+    L.g_a = L.g_b = L.g_skipsum = L.g_h0 = L.g_h1 = L.g_o = L.g_p = L.slab = 0;
+    L.slab_floats = 0;
+  }
+  L.total = cv.pos;
+  return L;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+struct Gemm {
+  WnGemmArgs a;
+  Gemm(int B, int T, int N, int JTtot) {
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.N = N; a.JTtot = JTtot; a.act = WN_ACT_LINEAR; a.epi = WN_EPI_PLAIN;
+  }
+  Gemm& seg(const float* x, int ldx, int K, int shift, const float* frag) {
+    WnSeg& s = a.seg[a.nseg++];
+    s.x = x; s.ldx = ldx; s.K = K; s.shift = shift; s.frag = frag;
+    s.vec = (ldx % 4 == 0 && K % 4 == 0 && al16(x)) ? 1 : 0;
+    return *this;
+  }
+  Gemm& bias(const float* b) { a.bias = b; return *this; }
+  Gemm& rowbias(const float* b, int ld) { a.rowbias = b; a.ld_rowbias = ld; return *this; }
+  Gemm& addc(const float* c, int ld) { a.addc = c; a.ld_addc = ld; return *this; }
+  Gemm& act(int act) { a.act = act; return *this; }
+  Gemm& dact(const float* ysaved, int ld, int act) { a.epi = WN_EPI_DACT; a.aux = ysaved; a.ld_aux = ld; a.act = act; return *this; }
+  Gemm& gate_bwd(const float* ag, int ld) { a.epi = WN_EPI_GATE_BWD; a.aux = ag; a.ld_aux = ld; return *this; }
+  int run(float* y, int ldy, hipStream_t s) {
+    a.y = y; a.ldy = ldy;
+    bool v = (a.N % 4 == 0) && (ldy % 4 == 0) && al16(y);
+    if (a.bias) v = v && al16(a.bias);
+    if (a.addc) v = v && (a.ld_addc % 4 == 0) && al16(a.addc);
+    if (a.aux) v = v && (a.ld_aux % 4 == 0) && al16(a.aux);
+    a.vec_out = v ? 1 : 0;
+    return wn_launch_gemm_rows(a, s);
+  }
+};
+
+// dW (+ optional db, + optional per-utterance column sums) through slabs
+int wgrad(const float* x, int ldx, int K, int shift, const float* g, int ldg, int N, int B, int T,
+          float* dW, float* db, float* per_batch, float* slab, hipStream_t s) {
+  WnWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = ldx; a.K = K; a.shift = shift; a.g = g; a.ldg = ldg; a.N = N; a.B = B; a.T = T;
+  a.splits_per_b = wn_wgrad_choose_splits(B, T, K, N);
+  const int nsplit = B * a.splits_per_b;
+  a.slab = slab;
+  a.slab_bias = (db || per_batch) ? slab + (int64_t)nsplit * K * N : nullptr;
+  int rc = wn_launch_wgrad(a, s);
+  if (rc) return rc;
+  if (dW) {
+    WnReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.slab = slab; r.nsplit = nsplit; r.K = K; r.N = N; r.out = dW; r.seg_len = K; r.seg_stride = 0;
+    r.accumulate = 0; r.replicate = 1; r.rep_stride = 0;
+    rc = wn_launch_reduce(r, s);
+    if (rc) return rc;
+  }
+  if (db) {
+    WnReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.slab = a.slab_bias; r.nsplit = nsplit; r.K = 1; r.N = N; r.out = db; r.seg_len = 1; r.seg_stride = 0;
+    r.accumulate = 0; r.replicate = 1; r.rep_stride = 0;
+    rc = wn_launch_reduce(r, s);
+    if (rc) return rc;
+  }
+  if (per_batch) rc = wn_launch_batch_reduce(a.slab_bias, B, a.splits_per_b, N, per_batch, s);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// one residual block, forward / backward, on explicit pointers (shared by the model
+// orchestration and the standalone WaveNetLayer entry points)
+// ------------------------------------------------------------------------------------------
+struct BlockPtrs {
+  // geometry
+  int B, T, KS, R, D, S, Cin, depth, act, residual;
+  int dil[16];
+  // raw parameters
+  const float* Wd[16]; const float* bd[16];
+  const float* br; const float* bs; const float* bc;
+  // images
+  const float* Fd[16]; const float* Bd[16]; int64_t Fd_stride[16], Bd_stride[16];
+  const float* Fr; const float* Br_;
+  const float* Fs; const float* Bs;
+  const float* Fc; const float* Bc;
+  int Cc;                   // time-varying condition channels (standalone layer) or 0
+  const float* cond;        // [rows][Cc]
+  const float* cb;          // [B][2D] per-utterance conditioning bias (model) or null
+  bool fused;
+};
+
+struct BlockBufs {
+  const float* x;           // [rows][Cin]
+  float* P[16];             // outputs of non-gated convs [rows][D]
+  float* U;                 // [rows][2D] scratch
+  float* AG;                // [rows][2D] saved (a|g) or null
+  float* Z; int ldz;        // gated activations
+  float* O;                 // [rows][R] pre-residual output or null
+  float* x_out;             // [rows][R]
+};
+
+int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
+  const int64_t rows = (int64_t)k.B * k.T;
+  const float* h = f.x;
+  int hc = k.Cin;
+  int rc;
+  for (int i = 0; i + 1 < k.depth; ++i) {
+    Gemm g(k.B, k.T, k.D, ceil32(k.D));
+    for (int t = 0; t < k.KS; ++t) g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[i], k.Fd[i] + t * k.Fd_stride[i]);
+    rc = g.bias(k.bd[i]).act(k.act).run(f.P[i], k.D, s);
+    if (rc) return rc;
+    h = f.P[i]; hc = k.D;
+  }
+  const int li = k.depth - 1;
+  if (k.fused && k.Cc == 0 && hc == k.R) {
+    WnLayerFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = h; a.frag_d = k.Fd[li]; a.frag_r = k.Fr; a.bias_d = k.bd[li]; a.bias_r = k.br; a.cb = k.cb;
+    a.x_out = f.x_out; a.o_out = f.O; a.z_out = f.Z; a.ldz = f.ldz; a.ag_out = f.AG;
+    a.res = (k.depth > 1) ? f.x : nullptr;
+    a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
+    return wn_launch_layer_fwd(a, s);
+  }
+  // composed path: u -> gate -> 1x1
+  {
+    Gemm g(k.B, k.T, 2 * k.D, ceil32(2 * k.D));
+    for (int t = 0; t < k.KS; ++t) g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[li], k.Fd[li] + t * k.Fd_stride[li]);
+    if (k.Cc > 0) g.seg(k.cond, k.Cc, k.Cc, 0, k.Fc);
+    g.bias(k.bd[li]);
+    if (k.cb) g.rowbias(k.cb, 2 * k.D);
+    rc = g.run(f.U, 2 * k.D, s);
+    if (rc) return rc;
+  }
+  rc = wn_launch_gate(f.U, rows, k.D, f.AG, f.Z, f.ldz, s);
+  if (rc) return rc;
+  {
+    Gemm g(k.B, k.T, k.R, ceil32(k.R));
+    g.seg(f.Z, f.ldz, k.D, 0, k.Fr).bias(k.br);
+    if (f.O) {
+      rc = g.run(f.O, k.R, s);
+      if (rc) return rc;
+      if (k.residual) return wn_launch_add(f.O, f.x, f.x_out, rows * k.R, s);
+      return hipMemcpyAsync(f.x_out, f.O, rows * k.R * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
+    }
+    if (k.residual) g.addc(f.x, k.Cin);
+    return g.run(f.x_out, k.R, s);
+  }
+}
+
+struct BlockGrads {
+  const float* g_xout;      // [rows][R] or null (treated as zero)
+  const float* g_skip;      // [rows][Sh] or null; Sh = S, or R when S == 0 (skip = pre-residual o)
+  float* g_o_tmp;           // [rows][R] scratch (needed when S == 0 and both grads exist)
+  float* g_u;               // [rows][2D] scratch
+  float* g_p;               // [2][rows][D] scratch (depth > 1), halves used alternately
+  float* g_x;               // [rows][Cin] out (may be null when not needed)
+  float* g_cond;            // [rows][Cc] out or null
+  float* dWd[16]; float* dbd[16];
+  float* dWr; float* dbr; float* dWs; float* dbs; float* dWc; float* dbc;
+  float* dcb;               // [B][2D] per-utterance sums of g_u (model conditioning) or null
+  float* slab;
+};
+
+int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, hipStream_t s) {
+  const int64_t rows = (int64_t)k.B * k.T;
+  int rc;
+  const int li = k.depth - 1;
+  const float* hin_last = (k.depth > 1) ? f.P[li - 1] : f.x;
+  const int hc_last = (k.depth > 1) ? k.D : k.Cin;
+  // gradient w.r.t. the conv1 output o
+  const float* g_o = g.g_xout;
+  if (k.S == 0 && g.g_skip) {
+    if (g.g_xout) {
+      rc = wn_launch_add(g.g_xout, g.g_skip, g.g_o_tmp, rows * k.R, s);
+      if (rc) return rc;
+      g_o = g.g_o_tmp;
+    } else {
+      g_o = g.g_skip;
+    }
+  }
+  // g_u = gate'( W_r g_o + W_s g_skip )
+  {
+    Gemm gm(k.B, k.T, k.D, ceil32(k.D));
+    if (g_o) gm.seg(g_o, k.R, k.R, 0, k.Br_);
+    if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, k.Bs);
+    if (gm.a.nseg == 0) {
+      rc = wn_launch_fill(g.g_u, 0.f, rows * 2 * k.D, s);
+    } else {
+      rc = gm.gate_bwd(f.AG, 2 * k.D).run(g.g_u, 2 * k.D, s);
+    }
+    if (rc) return rc;
+  }
+  // conv1 / conv_skip weight gradients
+  if (g_o) {
+    rc = wgrad(f.Z, f.ldz, k.D, 0, g_o, k.R, k.R, k.B, k.T, g.dWr, g.dbr, nullptr, g.slab, s);
+  } else {
+    rc = wn_launch_fill(g.dWr, 0.f, (int64_t)k.D * k.R, s);
+    if (!rc) rc = wn_launch_fill(g.dbr, 0.f, k.R, s);
+  }
+  if (rc) return rc;
+  if (k.S > 0 && g.dWs) {
+    if (g.g_skip) {
+      rc = wgrad(f.Z, f.ldz, k.D, 0, g.g_skip, k.S, k.S, k.B, k.T, g.dWs, g.dbs, nullptr, g.slab, s);
+    } else {
+      rc = wn_launch_fill(g.dWs, 0.f, (int64_t)k.D * k.S, s);
+      if (!rc) rc = wn_launch_fill(g.dbs, 0.f, k.S, s);
+    }
+    if (rc) return rc;
+  }
+  // time-varying condition (standalone layer)
+  if (k.Cc > 0) {
+    rc = wgrad(k.cond, k.Cc, k.Cc, 0, g.g_u, 2 * k.D, 2 * k.D, k.B, k.T, g.dWc, g.dbc, nullptr, g.slab, s);
+    if (rc) return rc;
+    if (g.g_cond) {
+      rc = Gemm(k.B, k.T, k.Cc, ceil32(k.Cc)).seg(g.g_u, 2 * k.D, 2 * k.D, 0, k.Bc).run(g.g_cond, k.Cc, s);
+      if (rc) return rc;
+    }
+  }
+  // dilated stack, last (gated) conv first
+  const float* gcur = g.g_u;       // gradient w.r.t. the pre-activation output of conv i
+  int gc = 2 * k.D;
+  for (int i = li; i >= 0; --i) {
+    const float* hin = (i > 0) ? f.P[i - 1] : f.x;
+    const int hc = (i > 0) ? k.D : k.Cin;
+    for (int t = 0; t < k.KS; ++t) {
+      const bool last_tap = (t == k.KS - 1);
+      rc = wgrad(hin, hc, hc, (k.KS - 1 - t) * k.dil[i], gcur, gc, gc, k.B, k.T,
+                 g.dWd[i] + (int64_t)t * hc * gc, last_tap ? g.dbd[i] : nullptr,
+                 (last_tap && i == li) ? g.dcb : nullptr, g.slab, s);
+      if (rc) return rc;
+    }
+    const bool need_gx = (i > 0) || g.g_x;
+    if (!need_gx) break;
+    Gemm gm(k.B, k.T, hc, ceil32(hc));
+    for (int t = 0; t < k.KS; ++t)
+      gm.seg(gcur, gc, gc, -(k.KS - 1 - t) * k.dil[i], k.Bd[i] + t * k.Bd_stride[i]);
+    if (i > 0) {
+      // output is the gradient w.r.t. P[i-1] (post-activation) -> fold act' in
+      float* dst = g.g_p + (int64_t)((i & 1) ? 0 : rows * k.D);
+      rc = gm.dact(f.P[i - 1], k.D, k.act).run(dst, k.D, s);
+      if (rc) return rc;
+      gcur = dst; gc = k.D;
+    } else {
+      if (k.residual && g.g_xout) gm.addc(g.g_xout, k.R);
+      rc = gm.run(g.g_x, hc, s);
+      if (rc) return rc;
+    }
+  }
+  (void)hin_last; (void)hc_last;
+  return WN_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI: plan
+// ==========================================================================================
+extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
+  if (!cfg) { wn_set_error("plan_create: null config"); return nullptr; }
+  const wn_config& c = *cfg;
+  // src/model.py:52-70 argument validation (the Python layer raises ValueError earlier)
+  if (c.kernel_size < 2) { wn_set_error("Kernel size must be at least 2."); return nullptr; }
+  if (c.layers_per_block < 1 || c.layers_per_block > 16) { wn_set_error("Layers per block must be in 1..16."); return nullptr; }
+  if (c.blocks < 1) { wn_set_error("Blocks must be at least 1."); return nullptr; }
+  if (c.channels < 1) { wn_set_error("channels must be positive"); return nullptr; }
+  {
+    const double lg = log((double)c.dilation_bound) / log((double)c.kernel_size);
+    int64_t pw = 1; int mp = 0;
+    while (pw < c.dilation_bound) { pw *= c.kernel_size; ++mp; }
+    if (pw != c.dilation_bound || mp < 1) { wn_set_error("dilation bound must be power of kernel_size."); return nullptr; }
+    (void)lg;
+  }
+  if (c.head == WN_HEAD_CATEGORICAL && c.num_mixtures != 0) { wn_set_error("Categorical sampling cannot be used with mixtures."); return nullptr; }
+  if (c.head != WN_HEAD_CATEGORICAL && c.num_mixtures < 1) { wn_set_error("Number of mixtures must be at least 1 for mixture heads."); return nullptr; }
+  if (c.n_final < 0 || c.n_final > WN_MAX_FINAL || c.n_mapping < 0 || c.n_mapping > WN_MAX_MAPPING) { wn_set_error("too many final / mapping layers"); return nullptr; }
+  if (c.bits < 1 || c.bits > 16) { wn_set_error("bits must be in 1..16"); return nullptr; }
+  if (c.kernel_size > 3) { wn_set_error("kernel_size > 3 is not supported by the gfx950 kernels"); return nullptr; }
+
+  wn_plan* p = new wn_plan();
+  p->c = c;
+  p->KS = c.kernel_size; p->R = c.channels; p->D = c.dilation_channels > 0 ? c.dilation_channels : c.channels;
+  p->S = c.skip_channels; p->N = c.blocks; p->LPB = c.layers_per_block;
+  p->Cout = c.num_mixtures > 0 ? 3 * c.num_mixtures : (1 << c.bits);
+  p->Sh = p->S > 0 ? p->S : p->R;
+  p->Hin = c.use_skip ? p->Sh : p->R;
+  p->Dp = ceil8(p->D);
+  // dilation schedule, src/model.py:79-81
+  {
+    int mp = 0; int64_t pw = 1;
+    while (pw < c.dilation_bound) { pw *= c.kernel_size; ++mp; }
+    for (int i = 0; i < p->LPB * p->N; ++i) {
+      int d = 1;
+      for (int e = 0; e < i % mp; ++e) d *= c.kernel_size;
+      p->dilations.push_back(d);
+    }
+  }
+  // mapped condition width, src/model.py:141-148
+  p->Cc = 0;
+  if (c.cond_inputs > 0) p->Cc = c.n_mapping > 0 ? c.mapping_channels[c.n_mapping - 1] : c.cond_inputs;
+
+  // ---- tensors in Keras creation order ----
+  p->causal = add_conv(p, p->KS, 1, p->R, 1);
+  for (int b = 0; b < p->N; ++b) {
+    BlockInfo bi;
+    int cin = p->R;
+    for (int i = 0; i < p->LPB; ++i) {
+      const int cout = (i == p->LPB - 1) ? 2 * p->D : p->D;
+      bi.dil.push_back(add_conv(p, p->KS, cin, cout, p->dilations[b * p->LPB + i]));
+      cin = cout;
+    }
+    bi.conv1 = add_conv(p, 1, p->D, p->R, 1);
+    bi.has_skip = p->S > 0;
+    if (bi.has_skip) bi.conv_skip = add_conv(p, 1, p->D, p->S, 1);
+    bi.has_cond = c.cond_inputs > 0;
+    if (bi.has_cond) bi.conv_cond = add_conv(p, 1, p->Cc, 2 * p->D, 1);
+    p->blocks.push_back(bi);
+  }
+  {
+    int cprev = p->Hin;
+    for (int i = 0; i < c.n_final; ++i) { p->finals.push_back(add_conv(p, 1, cprev, c.final_channels[i], 1)); cprev = c.final_channels[i]; }
+    p->finals.push_back(add_conv(p, 1, cprev, p->Cout, 1));
+  }
+  if (c.cond_inputs > 0) {
+    int cin = c.cond_inputs;
+    for (int j = 0; j < c.n_mapping; ++j) { p->mapping.push_back(add_dense(p, cin, c.mapping_channels[j])); cin = c.mapping_channels[j]; }
+  }
+  for (const TensorInfo& t : p->tensors) {
+    WnTensorDesc d; d.off = t.off; d.len = t.len;
+    p->tdesc.push_back(d);
+    if (t.is_kernel) p->kdesc.push_back(d);
+  }
+
+  // ---- weight images ----
+  add_images(p, p->causal, true, false);
+  for (BlockInfo& bi : p->blocks) {
+    for (ConvInfo& cv : bi.dil) add_images(p, cv, true, true);
+    add_images(p, bi.conv1, true, true);
+    if (bi.has_skip) add_images(p, bi.conv_skip, false, true);
+    if (bi.has_cond) add_images(p, bi.conv_cond, true, true);
+  }
+  for (ConvInfo& cv : p->finals) add_images(p, cv, true, true);
+  for (ConvInfo& cv : p->mapping) add_images(p, cv, true, true);
+  // folded skip sum: A[Sh][N*Dp], piece b = (conv_skip or conv1 of block b)^T
+  p->frag_skipF = p->frag_floats;
+  for (int b = 0; b < p->N; ++b) {
+    const ConvInfo& src = p->blocks[b].has_skip ? p->blocks[b].conv_skip : p->blocks[b].conv1;
+    WnPrepDesc d;
+    memset(&d, 0, sizeof(d));
+    d.src_off = p->tensors[src.kernel_t].off;
+    d.dst_off = p->frag_skipF;
+    d.I = p->Sh; d.KK = p->D; d.ld = p->Sh; d.transpose = 1;
+    d.q_off = b * (p->Dp / 8); d.j_off = 0; d.JT = ceil32(p->Sh);
+    p->prep.push_back(d);
+  }
+  p->frag_floats += (int64_t)wn_frag_floats(p->Sh, p->N * p->Dp);
+  p->fused_ok = wn_layer_fwd_supported(p->R, p->D, p->KS) != 0;
+  return p;
+}
+
+extern "C" void wn_plan_destroy(wn_plan* p) {
+  if (!p) return;
+  if (p->d_prep) (void)hipFree(p->d_prep);
+  if (p->d_tdesc) (void)hipFree(p->d_tdesc);
+  if (p->d_kdesc) (void)hipFree(p->d_kdesc);
+  for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+  delete p;
+}
+
+// ---- profiling hook: HIP events around every residual-block forward launch ----
+extern "C" int wn_prof_enable(wn_plan* p, int32_t max_launches) {
+  if (!p) return WN_E_INVALID;
+  for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+  p->prof_ev.clear();
+  p->prof_used = 0;
+  p->prof_on = max_launches > 0;
+  for (int i = 0; i < 2 * max_launches; ++i) {
+    hipEvent_t e;
+    WN_HIP_CHECK(hipEventCreate(&e));
+    p->prof_ev.push_back(e);
+  }
+  return WN_OK;
+}
+// average milliseconds per recorded launch (call after the stream has been synchronised)
+extern "C" int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms) {
+  if (!p || !launches || !avg_ms) return WN_E_INVALID;
+  double tot = 0.0;
+  int n = 0;
+  for (int i = 0; i + 1 < p->prof_used; i += 2) {
+    float ms = 0.f;
+    WN_HIP_CHECK(hipEventElapsedTime(&ms, p->prof_ev[i], p->prof_ev[i + 1]));
+    tot += ms; ++n;
+  }
+  *launches = n;
+  *avg_ms = n ? (float)(tot / n) : 0.f;
+  p->prof_used = 0;
+  return WN_OK;
+}
+
+extern "C" int64_t wn_plan_param_count(const wn_plan* p) { return p ? p->nparams : 0; }
+extern "C" int32_t wn_plan_num_tensors(const wn_plan* p) { return p ? (int32_t)p->tensors.size() : 0; }
+extern "C" int wn_plan_tensor_info(const wn_plan* p, int32_t idx, int64_t* offset, int64_t* len,
+                                   int32_t* ndim, int64_t* shape3, int32_t* is_kernel) {
+  if (!p || idx < 0 || idx >= (int32_t)p->tensors.size()) { wn_set_error("tensor_info: bad index"); return WN_E_INVALID; }
+  const TensorInfo& t = p->tensors[idx];
+  if (offset) *offset = t.off;
+  if (len) *len = t.len;
+  if (ndim) *ndim = t.ndim;
+  if (shape3) { shape3[0] = t.shape[0]; shape3[1] = t.shape[1]; shape3[2] = t.shape[2]; }
+  if (is_kernel) *is_kernel = t.is_kernel;
+  return WN_OK;
+}
+extern "C" int32_t wn_plan_receptive_field(const wn_plan* p) {
+  int64_t s = 0;
+  for (int d : p->dilations) s += d;
+  return (int32_t)(1 + s * (p->KS - 1) + 1);            // src/model.py:122
+}
+extern "C" int32_t wn_plan_out_channels(const wn_plan* p) { return p->Cout; }
+extern "C" int32_t wn_plan_dilation(const wn_plan* p, int32_t i) {
+  return (i >= 0 && i < (int32_t)p->dilations.size()) ? p->dilations[i] : -1;
+}
+extern "C" int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t T, int32_t training) {
+  if (!p || B < 1 || T < 1) return 0;
+  return make_layout(p, B, T, training != 0).total;
+}
+
+// ==========================================================================================
+// model forward / backward
+// ==========================================================================================
+namespace {
+
+BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* fragbase, int B, int T) {
+  BlockPtrs k;
+  memset(&k, 0, sizeof(k));
+  const BlockInfo& bi = p->blocks[b];
+  k.B = B; k.T = T; k.KS = p->KS; k.R = p->R; k.D = p->D; k.S = p->S; k.Cin = p->R; k.depth = p->LPB;
+  k.act = p->c.activation; k.residual = p->c.use_residual;
+  for (int i = 0; i < p->LPB; ++i) {
+    const ConvInfo& c = bi.dil[i];
+    k.dil[i] = c.dil;
+    k.Wd[i] = params + p->tensors[c.kernel_t].off;
+    k.bd[i] = params + p->tensors[c.bias_t].off;
+    k.Fd[i] = fragbase + c.fragF; k.Fd_stride[i] = c.fragF_stride;
+    k.Bd[i] = fragbase + c.fragB; k.Bd_stride[i] = c.fragB_stride;
+  }
+  k.br = params + p->tensors[bi.conv1.bias_t].off;
+  k.Fr = fragbase + bi.conv1.fragF; k.Br_ = fragbase + bi.conv1.fragB;
+  if (bi.has_skip) { k.bs = params + p->tensors[bi.conv_skip.bias_t].off; k.Bs = fragbase + bi.conv_skip.fragB; }
+  k.Cc = 0; k.cond = nullptr; k.cb = nullptr;
+  k.fused = p->fused_ok;
+  return k;
+}
+
+struct FwdCtx {
+  WsLayout L;
+  float* ws;
+  const float* frag;
+};
+
+// everything up to the logits; training keeps every activation
+int forward_core(wn_plan* p, const float* params, const float* x, bool prep, const float* cond, int B,
+                 int T, bool training, float* ws, const WsLayout& L, hipStream_t s) {
+  int rc = ensure_device_tables(p);
+  if (rc) return rc;
+  const int64_t rows = (int64_t)B * T;
+  float* fragbase = ws + L.frag;
+  if (prep) {
+    rc = wn_launch_prep_table(p->d_prep, (int)p->prep.size(), params, fragbase, s);
+    if (rc) return rc;
+  }
+  // bias of the folded skip sum = sum over blocks of conv_skip (or conv1) biases
+  if (prep && p->c.use_skip) {
+    const ConvInfo& c0 = p->blocks[0].has_skip ? p->blocks[0].conv_skip : p->blocks[0].conv1;
+    WnVecSumArgs v;
+    v.base = params; v.off0 = p->tensors[c0.bias_t].off;
+    v.stride = p->N > 1 ? (p->tensors[(p->blocks[1].has_skip ? p->blocks[1].conv_skip : p->blocks[1].conv1).bias_t].off - v.off0) : 0;
+    v.count = p->N; v.len = p->Sh; v.out = ws + L.bias_sum;
+    rc = wn_launch_vecsum(v, s);
+    if (rc) return rc;
+  }
+  // conditioning: mapping Dense stack + per-block time-invariant bias  (src/model.py:221-225,
+  // src/layers.py:203-204: conv_cond(repeat(m)) == per-utterance bias)
+  const float* m = cond;
+  if (p->c.cond_inputs > 0) {
+    if (!cond) { wn_set_error("Conditioning must be provided."); return WN_E_INVALID; }
+    int mc = p->c.cond_inputs;
+    for (size_t j = 0; j < p->mapping.size(); ++j) {
+      const ConvInfo& c = p->mapping[j];
+      rc = Gemm(1, B, c.cout, ceil32(c.cout)).seg(m, mc, mc, 0, fragbase + c.fragF)
+               .bias(params + p->tensors[c.bias_t].off).act(p->c.mapping_activation).run(ws + L.M[j], c.cout, s);
+      if (rc) return rc;
+      m = ws + L.M[j]; mc = c.cout;
+    }
+    for (int b = 0; b < p->N; ++b) {
+      const ConvInfo& c = p->blocks[b].conv_cond;
+      rc = Gemm(1, B, 2 * p->D, ceil32(2 * p->D)).seg(m, p->Cc, p->Cc, 0, fragbase + c.fragF)
+               .bias(params + p->tensors[c.bias_t].off).run(ws + L.cb + (int64_t)b * B * 2 * p->D, 2 * p->D, s);
+      if (rc) return rc;
+    }
+  }
+  // input causal conv, src/model.py:84-88,228 : KS taps with C_in = 1
+  {
+    Gemm g(B, T, p->R, ceil32(p->R));
+    for (int t = 0; t < p->KS; ++t)
+      g.seg(x, 1, 1, (p->KS - 1 - t), fragbase + p->causal.fragF + t * p->causal.fragF_stride);
+    rc = g.bias(params + p->tensors[p->causal.bias_t].off).run(ws + L.H[0], p->R, s);
+    if (rc) return rc;
+  }
+  if (p->Dp != p->D) {
+    rc = wn_launch_fill(ws + L.Z, 0.f, rows * p->N * p->Dp, s);
+    if (rc) return rc;
+  }
+  // residual blocks, src/model.py:230-234
+  for (int b = 0; b < p->N; ++b) {
+    BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
+    if (p->c.cond_inputs > 0) k.cb = ws + L.cb + (int64_t)b * B * 2 * p->D;
+    BlockBufs f;
+    memset(&f, 0, sizeof(f));
+    const int hi = training ? b : (b & 1), ho = training ? b + 1 : ((b + 1) & 1);
+    f.x = ws + L.H[hi];
+    for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
+    f.U = ws + L.U;
+    f.AG = training ? ws + L.AG[b] : nullptr;
+    f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+    f.O = nullptr;
+    f.x_out = ws + L.H[ho];
+    const bool prof = p->prof_on && p->prof_used + 2 <= (int)p->prof_ev.size();
+    if (prof) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
+    rc = block_forward(k, f, s);
+    if (rc) return rc;
+    if (prof) { (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s); p->prof_used += 2; }
+  }
+  // skip sum folded into one contraction over all blocks' gated activations (src/model.py:235-236
+  // with src/layers.py:216-219), or the last block output when use_skip is False
+  const float* hin;
+  if (p->c.use_skip) {
+    rc = Gemm(B, T, p->Sh, ceil32(p->Sh)).seg(ws + L.Z, p->N * p->Dp, p->N * p->Dp, 0, fragbase + p->frag_skipF)
+             .bias(ws + L.bias_sum).run(ws + L.skipsum, p->Sh, s);
+    if (rc) return rc;
+    hin = ws + L.skipsum;
+  } else {
+    hin = ws + L.H[training ? p->N : (p->N & 1)];
+  }
+  // head, src/model.py:105-119,237-238: conv -> activation, last conv linear (softmax applied later)
+  int hc = p->Hin;
+  for (size_t i = 0; i < p->finals.size(); ++i) {
+    const ConvInfo& c = p->finals[i];
+    const bool last = (i + 1 == p->finals.size());
+    float* dst = last ? ws + L.logits : ws + L.HA[i];
+    rc = Gemm(B, T, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
+             .bias(params + p->tensors[c.bias_t].off).act(last ? WN_ACT_LINEAR : p->c.activation).run(dst, c.cout, s);
+    if (rc) return rc;
+    hin = dst; hc = c.cout;
+  }
+  return WN_OK;
+}
+
+__global__ void wn_shift_split_kernel(const float* x_full, int B, int T, float* inputs, float* y_true) {
+  const int64_t n = (int64_t)B * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / T, t = i % T;
+    inputs[i] = x_full[b * (T + 1) + t];        // x[:, :-1]   src/model.py:321
+    y_true[i] = x_full[b * (T + 1) + t + 1];    // x[:, 1:]    src/model.py:319
+  }
+}
+
+int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float* ws, const WsLayout& L,
+               float* loss_out, hipStream_t s) {
+  const int64_t rows = (int64_t)B * T;
+  const float gscale = 1.0f / (float)global_batch;     // compute_average_loss, src/model.py:328-329
+  int rc;
+  float* g_logits = want_grad ? ws + L.g_a : nullptr;
+  if (p->c.head == WN_HEAD_CATEGORICAL) {
+    rc = wn_launch_quantize(ws + L.yt, reinterpret_cast<int32_t*>(ws + L.target), rows, p->c.bits, s);
+    if (rc) return rc;
+    rc = wn_launch_cat_loss(ws + L.logits, reinterpret_cast<const int32_t*>(ws + L.target), rows, p->Cout,
+                            gscale, ws + L.loss_rows, g_logits, s);
+  } else {
+    rc = wn_launch_mix_loss(ws + L.logits, ws + L.yt, rows, p->c.num_mixtures, p->c.bits,
+                            p->c.head == WN_HEAD_LOGISTIC ? 1 : 2, gscale, ws + L.loss_rows, g_logits, s);
+  }
+  if (rc) return rc;
+  return wn_launch_sum(ws + L.loss_rows, rows, gscale, loss_out, ws + L.sum_scratch, s);
+}
+
+}  // namespace
+
+extern "C" int wn_forward(wn_plan* p, const float* params, const float* x, const float* cond, int32_t B,
+                          int32_t T, float* out, float* logits_out, float* workspace, int64_t ws_floats,
+                          void* stream) {
+  if (!p || !params || !x || !workspace || B < 1 || T < 1) { wn_set_error("forward: bad arguments"); return WN_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  const WsLayout L = make_layout(p, B, T, false);
+  if (ws_floats < L.total) { wn_set_error("forward: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)L.total); return WN_E_INVALID; }
+  int rc = forward_core(p, params, x, true, cond, B, T, false, workspace, L, s);
+  if (rc) return rc;
+  const int64_t rows = (int64_t)B * T;
+  if (logits_out) WN_HIP_CHECK(hipMemcpyAsync(logits_out, workspace + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (out) {
+    if (p->c.head == WN_HEAD_CATEGORICAL) return wn_launch_softmax(workspace + L.logits, out, rows, p->Cout, s);
+    WN_HIP_CHECK(hipMemcpyAsync(out, workspace + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return WN_OK;
+}
+
+extern "C" int wn_eval_loss(wn_plan* p, const float* params, const float* x_full, const float* cond,
+                            int32_t B, int32_t T, int32_t global_batch, float* loss_out, float* pred_out,
+                            float* workspace, int64_t ws_floats, void* stream) {
+  if (!p || !params || !x_full || !workspace || !loss_out || B < 1 || T < 1) { wn_set_error("eval_loss: bad arguments"); return WN_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  const WsLayout L = make_layout(p, B, T, false);
+  if (ws_floats < L.total) { wn_set_error("eval_loss: workspace too small"); return WN_E_INVALID; }
+  const int64_t rows = (int64_t)B * T;
+  // inputs live in the (otherwise unused here) probs region
+  float* inputs = workspace + L.probs;
+  hipLaunchKernelGGL(wn_shift_split_kernel, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 4096)), dim3(256), 0, s,
+                     x_full, B, T, inputs, workspace + L.yt);
+  int rc = forward_core(p, params, inputs, true, cond, B, T, false, workspace, L, s);
+  if (rc) return rc;
+  rc = loss_stage(p, B, T, global_batch > 0 ? global_batch : B, false, workspace, L, loss_out, s);
+  if (rc) return rc;
+  if (pred_out) {
+    if (p->c.head == WN_HEAD_CATEGORICAL) return wn_launch_softmax(workspace + L.logits, pred_out, rows, p->Cout, s);
+    WN_HIP_CHECK(hipMemcpyAsync(pred_out, workspace + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return WN_OK;
+}
+
+extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_full, const float* cond,
+                                int32_t B, int32_t T, int32_t global_batch, int32_t n_replicas, float* grads,
+                                float* loss_out, float* pred_out, float* workspace, int64_t ws_floats,
+                                void* stream) {
+  if (!p || !params || !x_full || !workspace || !loss_out || !grads || B < 1 || T < 1) { wn_set_error("train_fwd_bwd: bad arguments"); return WN_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  const WsLayout L = make_layout(p, B, T, true);
+  if (ws_floats < L.total) { wn_set_error("train_fwd_bwd: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)L.total); return WN_E_INVALID; }
+  if (global_batch <= 0) global_batch = B;
+  if (n_replicas <= 0) n_replicas = 1;
+  float* ws = workspace;
+  const int64_t rows = (int64_t)B * T;
+  float* inputs = ws + L.probs;
+  hipLaunchKernelGGL(wn_shift_split_kernel, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 4096)), dim3(256), 0, s,
+                     x_full, B, T, inputs, ws + L.yt);
+  int rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
+  if (rc) return rc;
+  rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, s);
+  if (rc) return rc;
+  if (pred_out) {
+    if (p->c.head == WN_HEAD_CATEGORICAL) rc = wn_launch_softmax(ws + L.logits, pred_out, rows, p->Cout, s);
+    else rc = hipMemcpyAsync(pred_out, ws + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
+    if (rc) return rc;
+  }
+  const float* fragbase = ws + L.frag;
+  float* slab = ws + L.slab;
+
+  // ---- head backward ----
+  const float* g = ws + L.g_a;          // d loss / d logits
+  float* gnext = ws + L.g_b;
+  for (int i = (int)p->finals.size() - 1; i >= 0; --i) {
+    const ConvInfo& c = p->finals[i];
+    const float* xin = (i == 0) ? (p->c.use_skip ? ws + L.skipsum : ws + L.H[p->N]) : ws + L.HA[i - 1];
+    rc = wgrad(xin, c.cin, c.cin, 0, g, c.cout, c.cout, B, T, grads + p->tensors[c.kernel_t].off,
+               grads + p->tensors[c.bias_t].off, nullptr, slab, s);
+    if (rc) return rc;
+    Gemm gm(B, T, c.cin, ceil32(c.cin));
+    gm.seg(g, c.cout, c.cout, 0, fragbase + c.fragB);
+    float* dst = (i == 0) ? ws + L.g_skipsum : gnext;
+    if (i > 0) gm.dact(ws + L.HA[i - 1], c.cin, p->c.activation);
+    rc = gm.run(dst, c.cin, s);
+    if (rc) return rc;
+    if (i > 0) { const float* t = g; g = dst; gnext = const_cast<float*>(t); }
+  }
+  // ---- blocks, last to first ----
+  const float* g_skip = p->c.use_skip ? ws + L.g_skipsum : nullptr;
+  const float* g_xout = p->c.use_skip ? nullptr : ws + L.g_skipsum;   // head fed by the last block output
+  float* ghbuf[2] = {ws + L.g_h0, ws + L.g_h1};
+  if (p->c.cond_inputs > 0) {
+    rc = wn_launch_fill(ws + L.g_m0, 0.f, (int64_t)B * p->Cc, s);
+    if (rc) return rc;
+  }
+  const float* mlast = nullptr;
+  if (p->c.cond_inputs > 0) mlast = p->mapping.empty() ? cond : ws + L.M.back();
+  for (int b = p->N - 1; b >= 0; --b) {
+    BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
+    const BlockInfo& bi = p->blocks[b];
+    BlockBufs f;
+    memset(&f, 0, sizeof(f));
+    f.x = ws + L.H[b];
+    for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
+    f.AG = ws + L.AG[b];
+    f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+    BlockGrads bg;
+    memset(&bg, 0, sizeof(bg));
+    bg.g_xout = g_xout; bg.g_skip = g_skip; bg.g_o_tmp = ws + L.g_o; bg.g_u = ws + L.U; bg.g_p = ws + L.g_p;
+    bg.g_x = ghbuf[b & 1];
+    for (int i = 0; i < p->LPB; ++i) {
+      bg.dWd[i] = grads + p->tensors[bi.dil[i].kernel_t].off;
+      bg.dbd[i] = grads + p->tensors[bi.dil[i].bias_t].off;
+    }
+    bg.dWr = grads + p->tensors[bi.conv1.kernel_t].off; bg.dbr = grads + p->tensors[bi.conv1.bias_t].off;
+    if (bi.has_skip) { bg.dWs = grads + p->tensors[bi.conv_skip.kernel_t].off; bg.dbs = grads + p->tensors[bi.conv_skip.bias_t].off; }
+    bg.dcb = bi.has_cond ? ws + L.dcb : nullptr;
+    bg.slab = slab;
+    rc = block_backward(k, f, bg, s);
+    if (rc) return rc;
+    if (bi.has_cond) {
+      // conv_cond on the time-invariant mapped condition: dW_c = m^T dcb, db_c = sum_b dcb,
+      // g_m += dcb W_c^T
+      const ConvInfo& c = bi.conv_cond;
+      rc = wgrad(mlast, p->Cc, p->Cc, 0, ws + L.dcb, 2 * p->D, 2 * p->D, 1, B, grads + p->tensors[c.kernel_t].off,
+                 grads + p->tensors[c.bias_t].off, nullptr, slab, s);
+      if (rc) return rc;
+      rc = Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.dcb, 2 * p->D, 2 * p->D, 0, fragbase + c.fragB)
+               .addc(ws + L.g_m0, p->Cc).run(ws + L.g_m0, p->Cc, s);
+      if (rc) return rc;
+    }
+    g_xout = bg.g_x;
+  }
+  // ---- input causal conv: only weight gradients ----
+  for (int t = 0; t < p->KS; ++t) {
+    rc = wgrad(inputs, 1, 1, (p->KS - 1 - t), g_xout, p->R, p->R, B, T,
+               grads + p->tensors[p->causal.kernel_t].off + (int64_t)t * p->R,
+               (t == p->KS - 1) ? grads + p->tensors[p->causal.bias_t].off : nullptr, nullptr, slab, s);
+    if (rc) return rc;
+  }
+  // ---- mapping Dense stack backward ----
+  if (p->c.cond_inputs > 0) {
+    const float* gm_cur = ws + L.g_m0;      // gradient w.r.t. post-activation output of the last Dense
+    float* gm_other = ws + L.g_m1;
+    for (int j = (int)p->mapping.size() - 1; j >= 0; --j) {
+      const ConvInfo& c = p->mapping[j];
+      const float* yin = (j == 0) ? cond : ws + L.M[j - 1];
+      // pre-activation gradient g_pre = g * act'(M[j])  (tiny: B x width)
+      rc = wn_launch_dact_mul(gm_cur, ws + L.M[j], gm_other, (int64_t)B * c.cout, p->c.mapping_activation, s);
+      if (rc) return rc;
+      rc = wgrad(yin, c.cin, c.cin, 0, gm_other, c.cout, c.cout, 1, B, grads + p->tensors[c.kernel_t].off,
+                 grads + p->tensors[c.bias_t].off, nullptr, slab, s);
+      if (rc) return rc;
+      if (j > 0) {
+        float* dst = const_cast<float*>(gm_cur);
+        rc = Gemm(1, B, c.cin, ceil32(c.cin)).seg(gm_other, c.cout, c.cout, 0, fragbase + c.fragB).run(dst, c.cin, s);
+        if (rc) return rc;
+      }
+    }
+  }
+  // ---- L2 regulariser, src/model.py:331-334 ----
+  if (p->c.l2_reg_factor > 0.f) {
+    const float l2 = p->c.l2_reg_factor;
+    float* norms = ws + L.loss_rows;   // free by now
+    rc = wn_launch_sumsq(params, p->d_kdesc, (int)p->kdesc.size(), norms, s);
+    if (rc) return rc;
+    rc = wn_launch_sum(norms, (int64_t)p->kdesc.size(), l2 / (float)n_replicas, loss_out + 1, ws + L.sum_scratch, s);
+    if (rc) return rc;
+    rc = wn_launch_axpy_table(grads, params, p->d_kdesc, (int)p->kdesc.size(), 2.0f * l2 / (float)n_replicas, s);
+    if (rc) return rc;
+  } else {
+    rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
+    if (rc) return rc;
+  }
+  return WN_OK;
+}
+
+extern "C" int wn_adam_step(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,
+                            float lr, float beta1, float beta2, float eps, float clipnorm, float* scratch,
+                            void* stream) {
+  if (!p || !params || !grads || !m || !v || !scratch || step < 1) { wn_set_error("adam_step: bad arguments"); return WN_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_device_tables(p);
+  if (rc) return rc;
+  const int n = (int)p->tdesc.size();
+  if (clipnorm > 0.f) {
+    rc = wn_launch_sumsq(grads, p->d_tdesc, n, scratch, s);
+    if (rc) return rc;
+  }
+  const double alpha = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+  return wn_launch_adam(params, grads, m, v, p->d_tdesc, n, scratch, clipnorm, (float)alpha, beta1, beta2, eps, s);
+}
+
+// ==========================================================================================
+// generation: WaveNet.generate / _generation, src/model.py:241-307 (intended semantics:
+// SURVEY.md section 9 item 8 -- the reference's bad kwarg / rank bugs are not reproduced)
+// ==========================================================================================
+namespace {
+
+__global__ void wn_gen_shift_kernel(const float* win, const float* sample, int B, int RF, float* win_next,
+                                    float* out, int length, int step) {
+  const int64_t n = (int64_t)B * RF;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / RF), t = (int)(i % RF);
+    win_next[i] = (t == RF - 1) ? sample[b] : win[i + 1];
+    if (t == RF - 1) out[(int64_t)b * length + step] = sample[b];
+  }
+}
+
+__global__ void wn_gather_last_kernel(const float* logits, int B, int RF, int C, float* last) {
+  const int64_t n = (int64_t)B * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / C), c = (int)(i % C);
+    last[i] = logits[((int64_t)b * RF + (RF - 1)) * C + c];
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t wn_generate_workspace_floats(const wn_plan* p, int32_t B, int32_t queued) {
+  if (!p || B < 1) return 0;
+  (void)queued;
+  const int RF = wn_plan_receptive_field(p);
+  return make_layout(p, B, RF, false).total + 2 * align64((int64_t)B * RF) + 2 * align64((int64_t)B * p->Cout) + align64(B);
+}
+
+extern "C" int wn_generate(wn_plan* p, const float* params, const float* window, const float* cond, int32_t B,
+                           int32_t length, int32_t deterministic, int32_t queued, uint64_t seed, float* out,
+                           float* workspace, int64_t ws_floats, void* stream) {
+  if (!p || !params || !window || !out || !workspace || B < 1 || length < 0) { wn_set_error("generate: bad arguments"); return WN_E_INVALID; }
+  if (queued) { wn_set_error("generate: queued generation is not built yet"); return WN_E_UNSUPPORTED; }
+  hipStream_t s = (hipStream_t)stream;
+  const int RF = wn_plan_receptive_field(p);
+  const WsLayout L = make_layout(p, B, RF, false);
+  if (ws_floats < wn_generate_workspace_floats(p, B, 0)) { wn_set_error("generate: workspace too small"); return WN_E_INVALID; }
+  float* win[2] = {workspace + L.total, workspace + L.total + align64((int64_t)B * RF)};
+  float* last = win[1] + align64((int64_t)B * RF);
+  float* lastp = last + align64((int64_t)B * p->Cout);
+  float* samp = lastp + align64((int64_t)B * p->Cout);
+  WN_HIP_CHECK(hipMemcpyAsync(win[0], window, (int64_t)B * RF * sizeof(float), hipMemcpyDeviceToDevice, s));
+  const int M = p->c.num_mixtures;
+  for (int step = 0; step < length; ++step) {
+    int rc = forward_core(p, params, win[step & 1], step == 0, cond, B, RF, false, workspace, L, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wn_gather_last_kernel, dim3((B * p->Cout + 255) / 256), dim3(256), 0, s,
+                       workspace + L.logits, B, RF, p->Cout, last);
+    const float* pred = last;
+    if (p->c.head == WN_HEAD_CATEGORICAL) {
+      rc = wn_launch_softmax(last, lastp, B, p->Cout, s);     // the model output is probabilities
+      if (rc) return rc;
+      pred = lastp;
+    }
+    if (deterministic) rc = wn_launch_sample_det(pred, B, p->Cout, M, p->c.bits, samp, s);
+    else rc = wn_launch_sample_rand(pred, B, p->Cout, M, p->c.bits, p->c.head, seed, (uint64_t)step, samp, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wn_gen_shift_kernel, dim3((B * RF + 255) / 256), dim3(256), 0, s, win[step & 1], samp, B, RF,
+                       win[(step + 1) & 1], out, length, step);
+    WN_HIP_CHECK(hipGetLastError());
+  }
+  return WN_OK;
+}
+
+// ==========================================================================================
+// standalone residual block: WaveNetLayer.call, src/layers.py:178-224
+// ==========================================================================================
+namespace {
+
+struct LayerLayout {
+  // parameter offsets (floats) inside the layer's flat parameter buffer (Keras order)
+  int64_t Wd[16], bd[16], Wr, br, Ws, bs, Wc, bc, nparams;
+  int cin[16], cout[16];
+  // workspace
+  int64_t Fd[16], Bd[16], Fd_stride[16], Bd_stride[16], Fr, Br, Bs, Fs, Fc, Bc;
+  int64_t bias_u, U, O, g_u, g_o, g_p, slab, ws_total;
+  // saved
+  int64_t sP[16], sAG, sZ, saved_total;
+};
+
+int layer_layout(const wn_layer_desc* d, int B, int T, LayerLayout& L) {
+  if (!d || d->depth < 1 || d->depth > 16 || d->kernel_size < 2 || d->kernel_size > 3 || d->channels < 1) {
+    wn_set_error("layer: bad descriptor"); return WN_E_INVALID;
+  }
+  const int KS = d->kernel_size, R = d->channels, D = d->dilation_channels > 0 ? d->dilation_channels : R;
+  const int S = d->skip_channels, Cc = d->cond_channels;
+  const int64_t rows = (int64_t)B * T;
+  int64_t o = 0;
+  int cin = d->in_channels > 0 ? d->in_channels : R;
+  for (int i = 0; i < d->depth; ++i) {
+    const int cout = (i == d->depth - 1) ? 2 * D : D;
+    L.cin[i] = cin; L.cout[i] = cout;
+    L.Wd[i] = o; o += (int64_t)KS * cin * cout;
+    L.bd[i] = o; o += cout;
+    cin = cout;
+  }
+  L.Wr = o; o += (int64_t)D * R; L.br = o; o += R;
+  L.Ws = L.bs = L.Wc = L.bc = -1;
+  if (S > 0) { L.Ws = o; o += (int64_t)D * S; L.bs = o; o += S; }
+  if (Cc > 0) { L.Wc = o; o += (int64_t)Cc * 2 * D; L.bc = o; o += 2 * D; }
+  L.nparams = o;
+  Carver cv;
+  for (int i = 0; i < d->depth; ++i) {
+    L.Fd_stride[i] = (int64_t)wn_frag_floats(L.cout[i], L.cin[i]);
+    L.Bd_stride[i] = (int64_t)wn_frag_floats(L.cin[i], L.cout[i]);
+    L.Fd[i] = cv.take(KS * L.Fd_stride[i]);
+    L.Bd[i] = cv.take(KS * L.Bd_stride[i]);
+  }
+  L.Fr = cv.take((int64_t)wn_frag_floats(R, D));
+  L.Br = cv.take((int64_t)wn_frag_floats(D, R));
+  L.Fs = cv.take(S > 0 ? (int64_t)wn_frag_floats(S, D) : 0);
+  L.Bs = cv.take(S > 0 ? (int64_t)wn_frag_floats(D, S) : 0);
+  L.Fc = cv.take(Cc > 0 ? (int64_t)wn_frag_floats(2 * D, Cc) : 0);
+  L.Bc = cv.take(Cc > 0 ? (int64_t)wn_frag_floats(Cc, 2 * D) : 0);
+  L.bias_u = cv.take(2 * D);
+  L.U = cv.take(rows * 2 * D);
+  L.O = cv.take(rows * R);
+  L.g_u = L.U;                     // backward reuses the u scratch
+  L.g_o = L.O;
+  L.g_p = cv.take(d->depth > 1 ? 2 * rows * D : 0);
+  int64_t need = 0;
+  if (B > 0 && T > 0) {
+    for (int i = 0; i < d->depth; ++i) need = std::max(need, slab_need(B, T, L.cin[i], L.cout[i]));
+    need = std::max(need, slab_need(B, T, D, R));
+    if (S > 0) need = std::max(need, slab_need(B, T, D, S));
+    if (Cc > 0) need = std::max(need, slab_need(B, T, Cc, 2 * D));
+  }
+  L.slab = cv.take(need);
+  L.ws_total = cv.pos;
+  Carver sv;
+  for (int i = 0; i + 1 < d->depth; ++i) L.sP[i] = sv.take(rows * D);
+  L.sAG = sv.take(rows * 2 * D);
+  L.sZ = sv.take(rows * D);
+  L.saved_total = sv.pos;
+  return WN_OK;
+}
+
+int layer_prep(const wn_layer_desc* d, const LayerLayout& L, const float* params, float* ws, hipStream_t s) {
+  const int KS = d->kernel_size, R = d->channels, D = d->dilation_channels > 0 ? d->dilation_channels : R;
+  const int S = d->skip_channels, Cc = d->cond_channels;
+  auto one = [&](int64_t src, int64_t dst, int I, int KK, int ld, int tr) {
+    WnPrepDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.src_off = src; pd.dst_off = dst; pd.I = I; pd.KK = KK; pd.ld = ld; pd.transpose = tr;
+    pd.JT = (I + 31) / 32;
+    return wn_launch_prep_one(pd, params, ws, s);
+  };
+  int rc;
+  for (int i = 0; i < d->depth; ++i)
+    for (int t = 0; t < KS; ++t) {
+      const int64_t src = L.Wd[i] + (int64_t)t * L.cin[i] * L.cout[i];
+      if ((rc = one(src, L.Fd[i] + t * L.Fd_stride[i], L.cout[i], L.cin[i], L.cout[i], 1))) return rc;
+      if ((rc = one(src, L.Bd[i] + t * L.Bd_stride[i], L.cin[i], L.cout[i], L.cout[i], 0))) return rc;
+    }
+  if ((rc = one(L.Wr, L.Fr, R, D, R, 1))) return rc;
+  if ((rc = one(L.Wr, L.Br, D, R, R, 0))) return rc;
+  if (S > 0) {
+    if ((rc = one(L.Ws, L.Fs, S, D, S, 1))) return rc;
+    if ((rc = one(L.Ws, L.Bs, D, S, S, 0))) return rc;
+  }
+  if (Cc > 0) {
+    if ((rc = one(L.Wc, L.Fc, 2 * D, Cc, 2 * D, 1))) return rc;
+    if ((rc = one(L.Wc, L.Bc, Cc, 2 * D, 2 * D, 0))) return rc;
+    // u's bias = last dilated conv bias + conv_cond bias (src/layers.py:82-88,116-120,203-204)
+    WnVecSumArgs v;
+    v.base = params; v.off0 = L.bd[d->depth - 1]; v.stride = L.bc - L.bd[d->depth - 1]; v.count = 2; v.len = 2 * D;
+    v.out = ws + L.bias_u;
+    if ((rc = wn_launch_vecsum(v, s))) return rc;
+  }
+  return WN_OK;
+}
+
+void layer_ptrs(const wn_layer_desc* d, const LayerLayout& L, const float* params, const float* ws,
+                const float* cond, int B, int T, BlockPtrs& k) {
+  memset(&k, 0, sizeof(k));
+  const int R = d->channels, D = d->dilation_channels > 0 ? d->dilation_channels : R;
+  k.B = B; k.T = T; k.KS = d->kernel_size; k.R = R; k.D = D; k.S = d->skip_channels;
+  k.Cin = d->in_channels > 0 ? d->in_channels : R; k.depth = d->depth; k.act = d->activation; k.residual = d->residual;
+  for (int i = 0; i < d->depth; ++i) {
+    k.dil[i] = d->dilations[i];
+    k.Wd[i] = params + L.Wd[i]; k.bd[i] = params + L.bd[i];
+    k.Fd[i] = ws + L.Fd[i]; k.Bd[i] = ws + L.Bd[i]; k.Fd_stride[i] = L.Fd_stride[i]; k.Bd_stride[i] = L.Bd_stride[i];
+  }
+  k.br = params + L.br; k.Fr = ws + L.Fr; k.Br_ = ws + L.Br;
+  if (d->skip_channels > 0) { k.bs = params + L.bs; k.Fs = ws + L.Fs; k.Bs = ws + L.Bs; }
+  k.Cc = d->cond_channels; k.cond = cond; k.cb = nullptr;
+  if (k.Cc > 0) { k.Fc = ws + L.Fc; k.Bc = ws + L.Bc; k.bc = params + L.bc; k.bd[d->depth - 1] = ws + L.bias_u; }
+  k.fused = wn_layer_fwd_supported(R, D, d->kernel_size) != 0;
+}
+
+}  // namespace
+
+extern "C" int64_t wn_layer_param_count(const wn_layer_desc* d) {
+  LayerLayout L;
+  if (layer_layout(d, 0, 0, L)) return -1;
+  return L.nparams;
+}
+extern "C" int64_t wn_layer_saved_floats(const wn_layer_desc* d, int32_t B, int32_t T) {
+  LayerLayout L;
+  if (layer_layout(d, B, T, L)) return -1;
+  return L.saved_total;
+}
+extern "C" int64_t wn_layer_workspace_floats(const wn_layer_desc* d, int32_t B, int32_t T) {
+  LayerLayout L;
+  if (layer_layout(d, B, T, L)) return -1;
+  return L.ws_total;
+}
+
+extern "C" int wn_layer_fwd(const wn_layer_desc* d, const float* params, const float* x, const float* cond,
+                            int32_t B, int32_t T, float* x_out, float* skip_out, float* saved,
+                            float* workspace, void* stream) {
+  LayerLayout L;
+  int rc = layer_layout(d, B, T, L);
+  if (rc) return rc;
+  if (!params || !x || !x_out || !workspace) { wn_set_error("layer_fwd: null pointer"); return WN_E_INVALID; }
+  if (d->cond_channels > 0 && !cond) { wn_set_error("layer_fwd: condition tensor missing"); return WN_E_INVALID; }
+  if (d->residual && (d->in_channels > 0 ? d->in_channels : d->channels) != d->channels) {
+    wn_set_error("Residual connection must have the same shape as input"); return WN_E_INVALID;   // src/layers.py:161-162
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = layer_prep(d, L, params, workspace, s))) return rc;
+  BlockPtrs k;
+  layer_ptrs(d, L, params, workspace, cond, B, T, k);
+  const int D = k.D;
+  const int64_t rows = (int64_t)B * T;
+  BlockBufs f;
+  memset(&f, 0, sizeof(f));
+  f.x = x;
+  // without a saved buffer the intermediates live in scratch carved after the u buffer
+  float* sv = saved;
+  for (int i = 0; i + 1 < d->depth; ++i) f.P[i] = sv ? sv + L.sP[i] : nullptr;
+  f.U = workspace + L.U;
+  f.AG = sv ? sv + L.sAG : nullptr;
+  f.Z = sv ? sv + L.sZ : nullptr; f.ldz = D;
+  if (!sv) { wn_set_error("layer_fwd: saved buffer is required (holds z and the stack activations)"); return WN_E_INVALID; }
+  const bool skip_is_o = (d->skip_channels == 0);
+  f.O = (skip_is_o && skip_out) ? skip_out : nullptr;
+  f.x_out = x_out;
+  if ((rc = block_forward(k, f, s))) return rc;
+  if (!skip_is_o && skip_out) {
+    rc = Gemm(B, T, d->skip_channels, ceil32(d->skip_channels)).seg(f.Z, D, D, 0, k.Fs).bias(k.bs).run(skip_out, d->skip_channels, s);
+  }
+  (void)rows;
+  return rc;
+}
+
+extern "C" int wn_layer_bwd(const wn_layer_desc* d, const float* params, const float* x, const float* cond,
+                            const float* saved, const float* g_x_out, const float* g_skip, int32_t B, int32_t T,
+                            float* g_x, float* g_cond, float* g_params, float* workspace, void* stream) {
+  LayerLayout L;
+  int rc = layer_layout(d, B, T, L);
+  if (rc) return rc;
+  if (!params || !x || !saved || !g_params || !workspace) { wn_set_error("layer_bwd: null pointer"); return WN_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = layer_prep(d, L, params, workspace, s))) return rc;
+  BlockPtrs k;
+  layer_ptrs(d, L, params, workspace, cond, B, T, k);
+  BlockBufs f;
+  memset(&f, 0, sizeof(f));
+  f.x = x;
+  float* sv = const_cast<float*>(saved);
+  for (int i = 0; i + 1 < d->depth; ++i) f.P[i] = sv + L.sP[i];
+  f.AG = sv + L.sAG; f.Z = sv + L.sZ; f.ldz = k.D;
+  BlockGrads g;
+  memset(&g, 0, sizeof(g));
+  g.g_xout = g_x_out; g.g_skip = g_skip; g.g_o_tmp = workspace + L.g_o; g.g_u = workspace + L.g_u;
+  g.g_p = workspace + L.g_p; g.g_x = g_x; g.g_cond = g_cond;
+  for (int i = 0; i < d->depth; ++i) { g.dWd[i] = g_params + L.Wd[i]; g.dbd[i] = g_params + L.bd[i]; }
+  g.dWr = g_params + L.Wr; g.dbr = g_params + L.br;
+  if (d->skip_channels > 0) { g.dWs = g_params + L.Ws; g.dbs = g_params + L.bs; }
+  if (d->cond_channels > 0) { g.dWc = g_params + L.Wc; g.dbc = g_params + L.bc; }
+  g.slab = workspace + L.slab;
+  return block_backward(k, f, g, s);
+}
+
+// ==========================================================================================
+// elementwise entry points
+// ==========================================================================================
+extern "C" int wn_quantize(const float* x, int32_t* idx, int64_t n, int32_t bits, void* stream) {
+  return wn_launch_quantize(x, idx, n, bits, (hipStream_t)stream);
+}
+extern "C" int wn_dequantize(const int32_t* idx, float* x, int64_t n, int32_t bits, void* stream) {
+  return wn_launch_dequantize(idx, x, n, bits, (hipStream_t)stream);
+}
+extern "C" int wn_mulaw(const float* x, float* y, int64_t n, void* stream) { return wn_launch_mulaw(x, y, n, (hipStream_t)stream); }
+extern "C" int wn_inv_mulaw(const float* y, float* x, int64_t n, void* stream) { return wn_launch_inv_mulaw(y, x, n, (hipStream_t)stream); }
+extern "C" int wn_loss_fn(int32_t head, const void* target, const float* pred, int64_t rows, int32_t C,
+                          int32_t num_mixtures, int32_t bits, float* loss_rows, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (head == WN_HEAD_CATEGORICAL)
+    return wn_launch_cat_loss_probs(pred, (const int32_t*)target, rows, C, loss_rows, s);
+  if (head == WN_HEAD_LOGISTIC || head == WN_HEAD_GAUSSIAN)
+    return wn_launch_mix_loss(pred, (const float*)target, rows, num_mixtures, bits, head == WN_HEAD_LOGISTIC ? 1 : 2,
+                              1.0f, loss_rows, nullptr, s);
+  wn_set_error("Loss %d not implemented.", head);
+  return WN_E_UNSUPPORTED;
+}
+extern "C" int wn_sample_waveform(int32_t head, const float* pred, int64_t rows, int32_t C, int32_t num_mixtures,
+                                  int32_t bits, int32_t deterministic, uint64_t seed, uint64_t offset, float* out,
+                                  void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int M = head == WN_HEAD_CATEGORICAL ? 0 : num_mixtures;
+  if (deterministic) return wn_launch_sample_det(pred, rows, C, M, bits, out, s);
+  return wn_launch_sample_rand(pred, rows, C, M, bits, head, seed, offset, out, s);
+}

@@ -1,0 +1,494 @@
+"""WaveNet model: host-side mirror of src/model.py::WaveNet over the gfx950 HIP library.
+
+Same constructor keywords, method names, argument meaning, tensor layouts
+(channels-last ``(B, T, C)`` fp32) and exception types as the reference class; everything
+underneath is ``libwn_hip.so`` (no TensorFlow, no CPU fallback).  PyTorch is used only for
+device memory, streams and ``torch.distributed`` (RCCL).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import spec as _spec
+from .layers import WaveNetLayer
+from .optim import Adam
+
+
+class _ConvHandle:
+  """Read-only handle on one conv / dense of the flat parameter buffer (``.kernel``/``.bias``)."""
+
+  def __init__(self, model, name):
+    self._model, self._name = model, name
+
+  @property
+  def kernel(self):
+    return self._model._tensor(self._name + '/kernel')
+
+  @property
+  def bias(self):
+    return self._model._tensor(self._name + '/bias')
+
+  @property
+  def weights(self):
+    return [self.kernel, self.bias]
+
+
+class MeanSquaredError:
+  """Minimal stand-in for tf.keras.metrics.MeanSquaredError (train.py:227)."""
+  name = 'mean_squared_error'
+
+  def __init__(self):
+    self.reset_state()
+
+  def reset_state(self):
+    self.total, self.count = 0.0, 0
+
+  def update_state(self, y_true, y_pred):
+    self.total += float(torch.mean((y_true - y_pred) ** 2))
+    self.count += 1
+
+  def result(self):
+    return self.total / max(self.count, 1)
+
+
+class _Mean:
+  def __init__(self, name):
+    self.name = name
+    self.reset_state()
+
+  def reset_state(self):
+    self.total, self.count = 0.0, 0
+
+  def update_state(self, v):
+    self.total += float(v)
+    self.count += 1
+
+  def result(self):
+    return self.total / max(self.count, 1)
+
+
+class WaveNet(torch.nn.Module):
+  """WaveNet model class (src/model.py:11-556)."""
+
+  def __init__(self,
+               kernel_size: int = 2,
+               channels: int = 32,
+               blocks: int = 10,
+               layers_per_block: int = 1,
+               activation=None,
+               conditioning=None,
+               mapping_layers=None,
+               mapping_activation=None,
+               dropout: float = 0,
+               dilation_bound: int = 512,
+               num_mixtures=None,
+               sampling_function: str = 'categorical',
+               bits=8,
+               skip_channels=None,
+               dilation_channels=None,
+               use_residual=True,
+               use_skip=True,
+               final_layers_channels=None,
+               l2_reg_factor: float = 0,
+               device=None,
+               seed: int = 0):
+    super().__init__()
+    s = _spec.validate(kernel_size, channels, blocks, layers_per_block, activation, conditioning,
+                       mapping_layers, mapping_activation, dropout, dilation_bound, num_mixtures,
+                       sampling_function, bits, skip_channels, dilation_channels, use_residual,
+                       use_skip, final_layers_channels, l2_reg_factor)
+    self.spec = s
+    self.regularization = s.l2_reg_factor > 0
+    self.num_mixtures = num_mixtures
+    self.use_skip = use_skip
+    self.sampling_function = sampling_function
+    self.bits = bits
+    self.conditioning = conditioning
+    self.dropout = s.dropout
+    self.receptive_field = s.receptive_field            # src/model.py:122
+    self._device = torch.device(device) if device is not None else torch.device('cuda', 0)
+    self._seed = seed
+    self._plan = None
+    self._cond_inputs = None
+    self._names: List[str] = []
+    self._ws = {}
+    self.built = False
+    self.optimizer = None
+    self._metrics_from_compilation = []
+    self.loss_tracker = _Mean('loss')
+    self.reg_loss = _Mean('reg_loss') if self.regularization else None
+    self._sample_calls = 0
+    # structure handles (attribute names of the reference)
+    dil = s.dilations
+    lpb = s.layers_per_block
+    self.causal = _ConvHandle(self, 'causal')
+    self.wavenet_blocks = [
+        WaveNetLayer(kernel=s.kernel_size, channels=s.channels,
+                     dilation_rate=dil[b * lpb:(b + 1) * lpb], activation=s.activation,
+                     dilation_channels=s.dilation_channels, residual=s.use_residual,
+                     skip_channels=s.skip_channels, l2_reg_factor=s.l2_reg_factor, dropout=s.dropout,
+                     condition=conditioning is not None, _owner=(self, b))
+        for b in range(s.blocks)]
+    self.final = [_ConvHandle(self, f'final{i}') for i in range(len(s.final_layers_channels) + 1)]
+    self.mapping = [_ConvHandle(self, f'mapping{j}') for j in range(len(s.mapping_layers))] \
+        if conditioning == 'global' else None
+    if conditioning is None:
+      self.build(None)
+
+  # ------------------------------------------------------------------ build
+  def build(self, input_shape):
+    """Create the plan and the parameters (src/model.py:171-211).  With conditioning the
+    condition width is only known from the first input, as in Keras."""
+    if self.built:
+      return
+    s = self.spec
+    cond_inputs = 0
+    if self.conditioning is not None:
+      cond_inputs = int(input_shape[1][-1])
+    self._cond_inputs = cond_inputs
+    cfg = _lib.WnConfig()
+    cfg.kernel_size, cfg.channels, cfg.blocks = s.kernel_size, s.channels, s.blocks
+    cfg.layers_per_block = s.layers_per_block
+    cfg.activation = _lib.ACTIVATIONS[s.activation]
+    cfg.dilation_bound = s.dilation_bound
+    cfg.num_mixtures = s.num_mixtures or 0
+    cfg.head = _lib.HEADS[s.sampling_function]
+    cfg.bits = s.bits
+    cfg.skip_channels = s.skip_channels or 0
+    cfg.dilation_channels = s.dilation_channels or 0
+    cfg.use_residual, cfg.use_skip = int(s.use_residual), int(s.use_skip)
+    if len(s.final_layers_channels) > _lib.WN_MAX_FINAL or len(s.mapping_layers) > _lib.WN_MAX_MAPPING:
+      raise NotImplementedError('too many final / mapping layers')
+    cfg.n_final = len(s.final_layers_channels)
+    for i, c in enumerate(s.final_layers_channels):
+      cfg.final_channels[i] = c
+    cfg.cond_inputs = cond_inputs
+    cfg.n_mapping = len(s.mapping_layers)
+    for i, c in enumerate(s.mapping_layers):
+      cfg.mapping_channels[i] = c
+    cfg.mapping_activation = _lib.ACTIVATIONS[s.mapping_activation]
+    cfg.l2_reg_factor = s.l2_reg_factor
+    L = _lib.lib()
+    plan = L.wn_plan_create(C.byref(cfg))
+    if not plan:
+      raise ValueError(L.wn_last_error_string().decode())
+    self._plan = C.c_void_p(plan)
+    shapes = s.param_shapes(cond_inputs)
+    n = L.wn_plan_num_tensors(self._plan)
+    assert n == len(shapes), (n, len(shapes))
+    self._names = [nm for nm, _ in shapes]
+    self._offsets, self._shapes = [], []
+    off, ln = C.c_int64(), C.c_int64()
+    nd, isk = C.c_int32(), C.c_int32()
+    sh = (C.c_int64 * 3)()
+    for i, (nm, shp) in enumerate(shapes):
+      _lib.check(L.wn_plan_tensor_info(self._plan, i, C.byref(off), C.byref(ln), C.byref(nd), sh, C.byref(isk)))
+      assert tuple(sh[:nd.value]) == tuple(shp), (nm, tuple(sh[:nd.value]), shp)
+      self._offsets.append(off.value)
+      self._shapes.append(tuple(shp))
+    total = L.wn_plan_param_count(self._plan)
+    # Keras defaults: glorot-uniform kernels, zero biases (no initializer passed anywhere)
+    g = torch.Generator().manual_seed(self._seed)
+    flat = torch.zeros(total, dtype=torch.float32)
+    for nm, shp, o in zip(self._names, self._shapes, self._offsets):
+      if nm.endswith('kernel'):
+        if len(shp) == 3:
+          fan_in, fan_out = shp[0] * shp[1], shp[0] * shp[2]
+        else:
+          fan_in, fan_out = shp
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        cnt = int(np.prod(shp))
+        flat[o:o + cnt] = (torch.rand(cnt, generator=g) * 2 - 1) * lim
+    self.flat_params = torch.nn.Parameter(flat.to(self._device), requires_grad=False)
+    self.flat_grads = torch.zeros_like(self.flat_params)
+    self.built = True
+    if self.optimizer is not None:
+      self.optimizer.build(self)
+
+  def __del__(self):
+    try:
+      if self._plan is not None:
+        _lib.lib().wn_plan_destroy(self._plan)
+        self._plan = None
+    except Exception:  # interpreter shutdown
+      pass
+
+  # ------------------------------------------------------------------ weights
+  def _tensor(self, name):
+    i = self._names.index(name)
+    o, shp = self._offsets[i], self._shapes[i]
+    return self.flat_params.data[o:o + int(np.prod(shp))].view(*shp)
+
+  @property
+  def trainable_variables(self):
+    """Views on the flat buffer in Keras creation order."""
+    return [self._tensor(n) for n in self._names]
+
+  @property
+  def variable_names(self):
+    return list(self._names)
+
+  def get_weights(self):
+    return [t.detach().cpu().numpy().copy() for t in self.trainable_variables]
+
+  def set_weights(self, weights):
+    if len(weights) != len(self._names):
+      raise ValueError(f'expected {len(self._names)} arrays, got {len(weights)}')
+    for t, w in zip(self.trainable_variables, weights):
+      w = torch.as_tensor(np.asarray(w), dtype=torch.float32)
+      if tuple(w.shape) != tuple(t.shape):
+        raise ValueError(f'shape mismatch {tuple(w.shape)} vs {tuple(t.shape)}')
+      t.copy_(w)
+
+  def gradients(self):
+    """Gradient views matching trainable_variables (after train_step / loss_and_grads)."""
+    return [self.flat_grads[o:o + int(np.prod(s))].view(*s) for o, s in zip(self._offsets, self._shapes)]
+
+  # ------------------------------------------------------------------ compile
+  def compile(self, **kwargs):
+    """src/model.py:157-169."""
+    if 'loss' in kwargs:
+      raise ValueError('Loss must be set in the model init function.')
+    self._metrics_from_compilation = []
+    if 'metrics' in kwargs and kwargs['metrics'] is not None:
+      for metric in kwargs['metrics']:
+        self._metrics_from_compilation.append(metric)
+    self.loss_tracker = _Mean('loss')
+    if self.regularization:
+      self.reg_loss = _Mean('reg_loss')
+    self.optimizer = kwargs.get('optimizer')
+    if self.optimizer is not None and self.built:
+      self.optimizer.build(self)
+
+  @property
+  def metrics(self):
+    # the reference appends to the same list on every access (src/model.py:350-360); not reproduced
+    m = list(self._metrics_from_compilation) + [self.loss_tracker]
+    if self.regularization:
+      m.append(self.reg_loss)
+    return m
+
+  # ------------------------------------------------------------------ helpers
+  def _workspace(self, key, floats):
+    ws = self._ws.get(key)
+    if ws is None or ws.numel() < floats:
+      ws = torch.empty(int(floats), dtype=torch.float32, device=self._device)
+      self._ws[key] = ws
+    return ws
+
+  def _split_inputs(self, inputs):
+    if self.conditioning is not None:
+      x, cond = inputs
+      cond = torch.as_tensor(cond, dtype=torch.float32, device=self._device).contiguous()
+    else:
+      x, cond = inputs, None
+    x = torch.as_tensor(x, dtype=torch.float32, device=self._device).contiguous()
+    if x.dim() != 3 or x.shape[-1] != 1:
+      raise ValueError('input must have shape (batch, samples, 1)')
+    if not self.built:
+      self.build([tuple(x.shape), tuple(cond.shape)] if cond is not None else tuple(x.shape))
+    if cond is not None and (cond.dim() != 2 or cond.shape[0] != x.shape[0] or cond.shape[1] != self._cond_inputs):
+      raise ValueError('condition must have shape (batch, n_cond)')
+    return x, cond
+
+  # ------------------------------------------------------------------ call
+  def call(self, inputs, training=False):
+    """src/model.py:213-239: probabilities (categorical) or linear mixture parameters."""
+    if training and self.dropout > 0:
+      raise NotImplementedError('dropout > 0 in training mode is not built yet')
+    x, cond = self._split_inputs(inputs)
+    B, T = x.shape[0], x.shape[1]
+    L = _lib.lib()
+    ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
+    out = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device)
+    _lib.check(L.wn_forward(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                            _lib.ptr(out), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return out
+
+  def forward(self, inputs, training=False):
+    return self.call(inputs, training=training)
+
+  def logits(self, inputs):
+    """Pre-softmax head output (parity checks)."""
+    x, cond = self._split_inputs(inputs)
+    B, T = x.shape[0], x.shape[1]
+    L = _lib.lib()
+    ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
+    out = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device)
+    _lib.check(L.wn_forward(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                            None, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return out
+
+  # ------------------------------------------------------------------ training
+  @staticmethod
+  def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+      return dist.get_world_size()
+    return 1
+
+  def loss_and_grads(self, data, global_batch=None, n_replicas=None, want_pred=False):
+    """Forward + loss + backward of this replica's rows (src/model.py:319-335).
+
+    Fills ``self.flat_grads`` with d(sum_local l / B_global)/d(theta); returns
+    (loss tensor[2] = {loss, reg_loss}, pred or None, y_true)."""
+    if self.dropout > 0:
+      raise NotImplementedError('dropout > 0 in training mode is not built yet')
+    x, cond = self._split_inputs(data)
+    B, T = x.shape[0], x.shape[1] - 1
+    if T < 1:
+      raise ValueError('training data must hold at least 2 samples per utterance')
+    world = self._world()
+    if global_batch is None:
+      global_batch = B * world                         # compute_average_loss, src/model.py:328-329
+    if n_replicas is None:
+      n_replicas = world
+    L = _lib.lib()
+    ws = self._workspace('train', L.wn_plan_workspace_floats(self._plan, B, T, 1))
+    loss = torch.empty(2, dtype=torch.float32, device=self._device)
+    pred = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device) if want_pred else None
+    _lib.check(L.wn_train_fwd_bwd(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                                  int(global_batch), int(n_replicas), _lib.ptr(self.flat_grads),
+                                  _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return loss, pred, x[:, 1:, :]
+
+  def train_step(self, data):
+    """src/model.py:309-348.  Data-parallel: the flat gradient (and the two loss scalars) are
+    SUM-all-reduced over RCCL before the (replicated, deterministic) optimizer step."""
+    if self.optimizer is None:
+      raise RuntimeError('compile(optimizer=...) first')
+    want_metric = len(self._metrics_from_compilation) > 0
+    loss, pred, y_true = self.loss_and_grads(data, want_pred=want_metric)
+    world = self._world()
+    if world > 1:
+      import torch.distributed as dist
+      dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM)
+      dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+      loss[1] /= world              # every replica added the same reg_loss / n_replicas
+    self.optimizer.apply_gradients(self)
+    if want_metric:
+      sample = self.sample_waveform(pred)
+    lv = loss.tolist()
+    for metric in self.metrics:
+      if metric.name == 'loss':
+        metric.update_state(lv[0])
+      elif metric.name == 'reg_loss':
+        metric.update_state(lv[1])
+      else:
+        metric.update_state(y_true, sample)
+    return {m.name: m.result() for m in self.metrics}
+
+  def test_step(self, data):
+    """src/model.py:362-391."""
+    x, cond = self._split_inputs(data)
+    B, T = x.shape[0], x.shape[1] - 1
+    world = self._world()
+    L = _lib.lib()
+    ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
+    loss = torch.empty(2, dtype=torch.float32, device=self._device)
+    want_metric = len(self._metrics_from_compilation) > 0
+    pred = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device) if want_metric else None
+    _lib.check(L.wn_eval_loss(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                              B * world, _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(),
+                              _lib.stream_ptr()))
+    if world > 1:
+      import torch.distributed as dist
+      dist.all_reduce(loss[:1], op=dist.ReduceOp.SUM)
+    if want_metric:
+      sample = self.sample_waveform(pred)
+    for metric in self.metrics:
+      if metric.name == 'loss':
+        metric.update_state(float(loss[0]))
+      elif metric.name == 'reg_loss':
+        continue
+      else:
+        metric.update_state(x[:, 1:, :], sample)
+    return {m.name: m.result() for m in self.metrics if m.name != 'reg_loss'}
+
+  # ------------------------------------------------------------------ sampling / loss
+  def prepare_target(self, x):
+    """src/model.py:151-155: Discretization (bit-exact bucket indices) or identity."""
+    if self.num_mixtures is not None:
+      return x
+    x = torch.as_tensor(x, dtype=torch.float32, device=self._device).contiguous()
+    idx = torch.empty(x.shape, dtype=torch.int32, device=self._device)
+    _lib.check(_lib.lib().wn_quantize(_lib.ptr(x), _lib.ptr(idx), x.numel(), self.bits, _lib.stream_ptr()))
+    return idx
+
+  def sample_waveform(self, inputs, deterministic=False):
+    """src/model.py:393-503: (B,T,C_out) -> (B,T,1).  Stochastic draws use Philox keyed by the
+    reference's seed (4,2) -> 0x0402 plus a per-call offset (TF's stream is not reproducible)."""
+    pred = torch.as_tensor(inputs, dtype=torch.float32, device=self._device).contiguous()
+    if pred.dim() != 3:
+      raise ValueError('prediction must have shape (batch, samples, channels)')
+    B, T, Cc = pred.shape
+    out = torch.empty(B, T, 1, dtype=torch.float32, device=self._device)
+    self._sample_calls += 1
+    _lib.check(_lib.lib().wn_sample_waveform(_lib.HEADS[self.sampling_function], _lib.ptr(pred), B * T, Cc,
+                                              self.num_mixtures or 0, self.bits, int(bool(deterministic)),
+                                              0x0402, self._sample_calls, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+  def loss_fn(self, target, pred):
+    """src/model.py:505-551: per-(b,t) loss, shape (B,T)."""
+    pred = torch.as_tensor(pred, dtype=torch.float32, device=self._device).contiguous()
+    B, T, Cc = pred.shape
+    if self.sampling_function == 'categorical':
+      tgt = torch.as_tensor(target, device=self._device).to(torch.int32).contiguous()
+    else:
+      tgt = torch.as_tensor(target, dtype=torch.float32, device=self._device).contiguous()
+    if tgt.numel() != B * T:
+      raise ValueError('target must have shape (batch, samples, 1)')
+    out = torch.empty(B, T, dtype=torch.float32, device=self._device)
+    _lib.check(_lib.lib().wn_loss_fn(_lib.HEADS[self.sampling_function], _lib.ptr(tgt), _lib.ptr(pred), B * T, Cc,
+                                      self.num_mixtures or 0, self.bits, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+  # ------------------------------------------------------------------ generation
+  def generate(self, length, batch_size: int = 1, condition=None, sample=None,
+               use_queues=False, deterministic=False):
+    """src/model.py:258-307 (intended semantics; the reference's kwarg / rank bugs are not
+    reproduced).  Returns (B, length, 1)."""
+    if self.conditioning is not None and condition is None:
+      raise ValueError('Conditioning must be provided.')
+    if condition is not None:
+      condition = torch.as_tensor(condition, dtype=torch.float32, device=self._device).contiguous()
+    if sample is not None:
+      sample = torch.as_tensor(sample, dtype=torch.float32, device=self._device).contiguous()
+    if condition is not None and sample is not None:
+      if condition.shape[0] != sample.shape[0]:
+        raise ValueError('Condition and sample must have same batch size.')
+    if condition is not None:
+      batch_size = condition.shape[0]
+    if sample is not None:
+      batch_size = sample.shape[0]
+    rf = self.receptive_field
+    if sample is None:
+      if deterministic:
+        sample = torch.zeros(batch_size, rf, 1, device=self._device)
+      else:
+        g = torch.Generator(device='cpu').manual_seed(0x0402)
+        sample = torch.randn(batch_size, rf, 1, generator=g).to(self._device)
+    if sample.shape[1] != rf:
+      if sample.shape[1] < rf:
+        raise ValueError('sample must hold at least receptive_field samples')
+      sample = sample[:, -rf:, :].contiguous()
+    if not self.built:
+      self.build([tuple(sample.shape), tuple(condition.shape)] if condition is not None else tuple(sample.shape))
+    L = _lib.lib()
+    ws = self._workspace('gen', L.wn_generate_workspace_floats(self._plan, batch_size, int(bool(use_queues))))
+    out = torch.empty(batch_size, int(length), 1, dtype=torch.float32, device=self._device)
+    _lib.check(L.wn_generate(self._plan, _lib.ptr(self.flat_params), _lib.ptr(sample), _lib.ptr(condition),
+                             batch_size, int(length), int(bool(deterministic)), int(bool(use_queues)), 0x0402,
+                             _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return out
+
+  def compute_receptive_field(self, sampling_frequency):
+    """src/model.py:553-556."""
+    return self.receptive_field / sampling_frequency
