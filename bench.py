@@ -40,7 +40,12 @@ def cpu_baseline(budget_s: float = 20.0):
   """Restated-reference CPU baseline: oracle train step on configs[0] (1 x 16000)."""
   import torch
   from oracle import wavenet_oracle as O
-  cores = os.cpu_count() or 1
+  # the GPU box exposes every host core but one GPU's share is 16 (more threads only thrash)
+  try:
+    avail = len(os.sched_getaffinity(0))
+  except AttributeError:
+    avail = os.cpu_count() or 1
+  cores = max(1, min(avail, 16))
   torch.set_num_threads(cores)
   ocfg = O.OracleConfig(**CFG1)
   params = O.init_params(ocfg, seed=0, bias_range=0.0)

@@ -241,63 +241,66 @@ int wn_launch_cat_loss_probs(const float* probs, const int32_t* target, int64_t 
   return WN_OK;
 }
 
-// mixture losses, one thread per (b,t) row; M <= 32
+// mixture losses, one thread per (b,t) row; M <= 32.  Evaluated in double: with bits = 16 the
+// half-bin (src/model.py:538) is 7.6e-6, so sigmoid(a) - sigmoid(b) cancels ~5 digits and an
+// fp32 evaluation (the reference's own included) carries 1e-3..1e-2 relative noise per term.
 #define WN_MAXMIX 32
+__device__ __forceinline__ double wn_sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 __global__ void wn_mix_loss_kernel(const float* pred, const float* y, int64_t rows, int M, int bits,
                                    int kind, float gscale, float* loss_rows, float* g_pred) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   const float* p = pred + row * 3 * M;
-  const float yy = y[row];
-  float w[WN_MAXMIX], comp[WN_MAXMIX];
-  float wm = -INFINITY;
-  for (int k = 0; k < M; ++k) wm = fmaxf(wm, p[k]);
-  float wz = 0.f;
-  for (int k = 0; k < M; ++k) { w[k] = expf(p[k] - wm); wz += w[k]; }
-  const float winv = 1.0f / wz;
-  const float halfbit = 0.5f / (float)(1 << bits);                       // src/model.py:538
-  const float sqrt2pi = sqrtf(2.0f * 3.14159265359f);                    // src/model.py:9
-  float lik = 0.f;
+  const double yy = (double)y[row];
+  double w[WN_MAXMIX], comp[WN_MAXMIX];
+  double wm = -INFINITY;
+  for (int k = 0; k < M; ++k) wm = fmax(wm, (double)p[k]);
+  double wz = 0.0;
+  for (int k = 0; k < M; ++k) { w[k] = exp((double)p[k] - wm); wz += w[k]; }
+  const double winv = 1.0 / wz;
+  const double halfbit = 0.5 / (double)(1 << bits);                      // src/model.py:538
+  const double sqrt2pi = sqrt(2.0 * 3.14159265359);                      // src/model.py:9
+  double lik = 0.0;
   for (int k = 0; k < M; ++k) {
     w[k] *= winv;
-    const float mu = p[M + k];
-    const float ls = fmaxf(p[2 * M + k], -7.0f);
+    const double mu = (double)p[M + k];
+    const double ls = fmax((double)p[2 * M + k], -7.0);
     if (kind == 1) {
-      const float inv = expf(-ls);
-      comp[k] = wn_sigmoid((yy - mu + halfbit) * inv) - wn_sigmoid((yy - mu - halfbit) * inv);
+      const double inv = exp(-ls);
+      comp[k] = wn_sigmoid_d((yy - mu + halfbit) * inv) - wn_sigmoid_d((yy - mu - halfbit) * inv);
     } else {
-      const float sc = expf(ls);
-      const float xx = fminf((yy - mu) / sc, 1e8f);
-      comp[k] = expf(-0.5f * xx * xx) / (sc * sqrt2pi);
+      const double sc = exp(ls);
+      const double xx = fmin((yy - mu) / sc, 1e8);
+      comp[k] = exp(-0.5 * xx * xx) / (sc * sqrt2pi);
     }
     lik += w[k] * comp[k];
   }
-  loss_rows[row] = -logf(lik);
+  loss_rows[row] = (float)(-log(lik));
   if (!g_pred) return;
   float* g = g_pred + row * 3 * M;
-  const float dl = -gscale / lik;                                        // dL/dlik
+  const double dl = -(double)gscale / lik;                               // dL/dlik
   for (int k = 0; k < M; ++k) {
-    const float mu = p[M + k];
-    const float lsr = p[2 * M + k];
-    const float ls = fmaxf(lsr, -7.0f);
-    const float lsmask = lsr >= -7.0f ? 1.f : 0.f;
-    g[k] = dl * (w[k] * comp[k] - w[k] * lik);
+    const double mu = (double)p[M + k];
+    const double lsr = (double)p[2 * M + k];
+    const double ls = fmax(lsr, -7.0);
+    const double lsmask = lsr >= -7.0 ? 1.0 : 0.0;
+    g[k] = (float)(dl * (w[k] * comp[k] - w[k] * lik));
     if (kind == 1) {
-      const float inv = expf(-ls);
-      const float a = (yy - mu + halfbit) * inv, b = (yy - mu - halfbit) * inv;
-      const float sa = wn_sigmoid(a), sb = wn_sigmoid(b);
-      const float da = sa * (1.f - sa), db = sb * (1.f - sb);
-      g[M + k] = dl * (-w[k] * inv * (da - db));
-      g[2 * M + k] = dl * lsmask * (-w[k] * (a * da - b * db));
+      const double inv = exp(-ls);
+      const double a = (yy - mu + halfbit) * inv, b = (yy - mu - halfbit) * inv;
+      const double sa = wn_sigmoid_d(a), sb = wn_sigmoid_d(b);
+      const double da = sa * (1.0 - sa), db = sb * (1.0 - sb);
+      g[M + k] = (float)(dl * (-w[k] * inv * (da - db)));
+      g[2 * M + k] = (float)(dl * lsmask * (-w[k] * (a * da - b * db)));
     } else {
-      const float sc = expf(ls);
-      const float xr = (yy - mu) / sc;
-      const float xx = fminf(xr, 1e8f);
-      const float xmask = xr <= 1e8f ? 1.f : 0.f;
-      const float pdf = comp[k];
+      const double sc = exp(ls);
+      const double xr = (yy - mu) / sc;
+      const double xx = fmin(xr, 1e8);
+      const double xmask = xr <= 1e8 ? 1.0 : 0.0;
+      const double pdf = comp[k];
       // d pdf/d mu = pdf * xx / sc ; d pdf/d ls = pdf * (xx^2 - 1)
-      g[M + k] = dl * w[k] * pdf * xx / sc * xmask;
-      g[2 * M + k] = dl * lsmask * w[k] * pdf * (xx * xx * xmask - 1.f);
+      g[M + k] = (float)(dl * w[k] * pdf * xx / sc * xmask);
+      g[2 * M + k] = (float)(dl * lsmask * w[k] * pdf * (xx * xx * xmask - 1.0));
     }
   }
 }
@@ -547,8 +550,8 @@ __global__ void wn_gate_kernel(const float* u, int64_t rows, int D, float* ag, f
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / D;
     const int c = (int)(i % D);
-    const float a = tanhf(u[r * 2 * D + c]);
-    const float g = wn_sigmoid(u[r * 2 * D + D + c]);
+    const float a = wn_tanh_fast(u[r * 2 * D + c]);
+    const float g = wn_sigmoid_fast(u[r * 2 * D + D + c]);
     if (ag) { ag[r * 2 * D + c] = a; ag[r * 2 * D + D + c] = g; }
     if (z) z[r * ldz + c] = a * g;
   }

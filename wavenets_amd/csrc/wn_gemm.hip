@@ -79,7 +79,7 @@ int wn_launch_vecsum(WnVecSumArgs a, hipStream_t s) {
 // rows GEMM
 // ------------------------------------------------------------------------------------------
 template <int JT>
-__global__ __launch_bounds__(256) void wn_gemm_rows_kernel(WnGemmArgs a) {
+__global__ __launch_bounds__(256, (JT >= 8 ? 2 : (JT >= 4 ? 3 : 4))) void wn_gemm_rows_kernel(WnGemmArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int tiles_per_b = (a.T + 31) >> 5;
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256) void wn_gemm_rows_kernel(WnGemmArgs a) {
     const float* xrow = sx + ((int64_t)b * a.T + (valid ? ts : 0)) * sldx;
     const int nq = (sK + 7) >> 3;
     const f32x4* fr = reinterpret_cast<const f32x4*>(sfrag) + (int64_t)jb * 64 + lane;
-    for (int q = 0; q < nq; ++q) {
+
+    // operands of one k-quad: the lane's 4 activations and JT weight fragments
+    auto load_x = [&](int q) -> f32x4 {
       const int k = 8 * q + 4 * h;
       f32x4 xv = {0.f, 0.f, 0.f, 0.f};
       if (valid) {
@@ -123,17 +125,41 @@ __global__ __launch_bounds__(256) void wn_gemm_rows_kernel(WnGemmArgs a) {
           if (k + 3 < sK) xv.w = xrow[k + 3];
         }
       }
+      return xv;
+    };
+    auto load_a = [&](int q, f32x4 (&av)[JT]) {
       wn_static_for<JT>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        if (jb + j < a.JTtot) {   // block-uniform
-          const f32x4 av = fr[((int64_t)q * a.JTtot + j) * 64];
-          acc[j] = wn_mfma(av.x, xv.x, acc[j]);
-          acc[j] = wn_mfma(av.y, xv.y, acc[j]);
-          acc[j] = wn_mfma(av.z, xv.z, acc[j]);
-          acc[j] = wn_mfma(av.w, xv.w, acc[j]);
+        if (jb + j < a.JTtot) av[j] = fr[((int64_t)q * a.JTtot + j) * 64];   // block-uniform
+      });
+    };
+    auto compute = [&](const f32x4& xv, const f32x4 (&av)[JT]) {
+      wn_static_for<JT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (jb + j < a.JTtot) {
+          acc[j] = wn_mfma(av[j].x, xv.x, acc[j]);
+          acc[j] = wn_mfma(av[j].y, xv.y, acc[j]);
+          acc[j] = wn_mfma(av[j].z, xv.z, acc[j]);
+          acc[j] = wn_mfma(av[j].w, xv.w, acc[j]);
         }
       });
+    };
+    // software pipeline, one k-quad ahead, two named register sets (no copies)
+    f32x4 x0, x1, a0[JT], a1[JT];
+    x0 = load_x(0);
+    load_a(0, a0);
+    int q = 0;
+    for (; q + 2 <= nq; q += 2) {
+      x1 = load_x(q + 1);
+      load_a(q + 1, a1);
+      compute(x0, a0);
+      if (q + 2 < nq) {
+        x0 = load_x(q + 2);
+        load_a(q + 2, a0);
+      }
+      compute(x1, a1);
     }
+    if (q < nq) compute(x0, a0);
   }
 
   if (t >= a.T) return;
@@ -236,21 +262,19 @@ int wn_launch_gemm_rows(const WnGemmArgs& a, hipStream_t s) {
 #define WG_TM 2
 #define WG_TN 4
 
-__global__ __launch_bounds__(256) void wn_wgrad_kernel(WnWgradArgs a, int nkb, int nnb) {
+// one wave: rows [r0, r1) of utterance b, output block (k0.., n0..) of WG_TM x WG_TN tiles
+struct WnWgUnit {
+  const float* x; int ldx; int K; int shift;
+  const float* g; int ldg; int N;
+  int T; int b; int r0; int r1; int k0; int n0;
+  float* out; int out_ld;         // dW block origin is out[k * out_ld + n]
+  float* bias;                    // db[n] or null
+};
+
+__device__ __forceinline__ void wn_wgrad_body(const WnWgUnit& a) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
   const int tl = lane & 31, h = lane >> 5;
-  const int nsplit = a.B * a.splits_per_b;
-  const int split = blockIdx.x * 4 + wave;
-  if (split >= nsplit) return;                         // wave-uniform
-  const int kb = blockIdx.y / nnb, nb = blockIdx.y % nnb;
-  const int k0 = kb * 32 * WG_TM, n0 = nb * 32 * WG_TN;
-  const int b = split / a.splits_per_b;
-  const int sp = split % a.splits_per_b;
-  int len = (a.T + a.splits_per_b - 1) / a.splits_per_b;
-  len = (len + 1) & ~1;
-  const int r0 = sp * len;
-  const int r1 = min(a.T, r0 + len);
+  const int k0 = a.k0, n0 = a.n0, r0 = a.r0, r1 = a.r1;
 
   f32x16 acc[WG_TM][WG_TN];
 #pragma unroll
@@ -263,32 +287,61 @@ __global__ __launch_bounds__(256) void wn_wgrad_kernel(WnWgradArgs a, int nkb, i
 #pragma unroll
   for (int j = 0; j < WG_TN; ++j) bsum[j] = 0.f;
 
-  const float* xb = a.x + (int64_t)b * a.T * a.ldx;
-  const float* gb = a.g + (int64_t)b * a.T * a.ldg;
-  for (int tt = r0; tt < r1; tt += 2) {
-    const int t = tt + h;
-    const int ts = t - a.shift;
-    const bool tv = t < r1;
-    const bool xv = tv && ts >= 0 && ts < a.T;
-    float av[WG_TM], bv[WG_TN];
+  const float* xb = a.x + (int64_t)a.b * a.T * a.ldx;
+  const float* gb = a.g + (int64_t)a.b * a.T * a.ldg;
+  // WG_CH time-step pairs per chunk; the next chunk's operands are loaded before the current
+  // chunk's MFMAs (two named register sets)
+  constexpr int WG_CH = 4;
+  // running row pointers (advanced by whole chunks) + channel masks hoisted out of the loop
+  const int64_t xstep = (int64_t)2 * a.ldx, gstep = (int64_t)2 * a.ldg;
+  bool kin[WG_TM], nin[WG_TN];
 #pragma unroll
-    for (int i = 0; i < WG_TM; ++i) {
-      const int c = k0 + 32 * i + tl;
-      av[i] = (xv && c < a.K) ? xb[(int64_t)ts * a.ldx + c] : 0.f;
+  for (int i = 0; i < WG_TM; ++i) kin[i] = (k0 + 32 * i + tl) < a.K;
+#pragma unroll
+  for (int j = 0; j < WG_TN; ++j) nin[j] = (n0 + 32 * j + tl) < a.N;
+  const float* xbase = xb + k0 + tl;
+  const float* gbase = gb + n0 + tl;
+  auto load_chunk = [&](int tt0, float (&av)[WG_CH][WG_TM], float (&bv)[WG_CH][WG_TN]) {
+    const float* px = xbase + (int64_t)(tt0 + h - a.shift) * a.ldx;
+    const float* pg = gbase + (int64_t)(tt0 + h) * a.ldg;
+#pragma unroll
+    for (int c = 0; c < WG_CH; ++c) {
+      const int t = tt0 + 2 * c + h;
+      const int ts = t - a.shift;
+      const bool tv = t < r1;
+      const bool xv = tv && ts >= 0 && ts < a.T;
+#pragma unroll
+      for (int i = 0; i < WG_TM; ++i) av[c][i] = (xv && kin[i]) ? px[c * xstep + 32 * i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < WG_TN; ++j) bv[c][j] = (tv && nin[j]) ? pg[c * gstep + 32 * j] : 0.f;
     }
+  };
+  auto compute_chunk = [&](const float (&av)[WG_CH][WG_TM], const float (&bv)[WG_CH][WG_TN]) {
 #pragma unroll
-    for (int j = 0; j < WG_TN; ++j) {
-      const int n = n0 + 32 * j + tl;
-      bv[j] = (tv && n < a.N) ? gb[(int64_t)t * a.ldg + n] : 0.f;
-      bsum[j] += bv[j];
+    for (int c = 0; c < WG_CH; ++c) {
+#pragma unroll
+      for (int j = 0; j < WG_TN; ++j) bsum[j] += bv[c][j];
+#pragma unroll
+      for (int i = 0; i < WG_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < WG_TN; ++j) acc[i][j] = wn_mfma(av[c][i], bv[c][j], acc[i][j]);
     }
-#pragma unroll
-    for (int i = 0; i < WG_TM; ++i)
-#pragma unroll
-      for (int j = 0; j < WG_TN; ++j) acc[i][j] = wn_mfma(av[i], bv[j], acc[i][j]);
+  };
+  {
+    float av0[WG_CH][WG_TM], bv0[WG_CH][WG_TN], av1[WG_CH][WG_TM], bv1[WG_CH][WG_TN];
+    constexpr int STEP = 2 * WG_CH;
+    int tt = r0;
+    if (tt < r1) load_chunk(tt, av0, bv0);
+    for (; tt < r1; tt += 2 * STEP) {
+      if (tt + STEP < r1) load_chunk(tt + STEP, av1, bv1);
+      compute_chunk(av0, bv0);
+      if (tt + STEP < r1) {
+        if (tt + 2 * STEP < r1) load_chunk(tt + 2 * STEP, av0, bv0);
+        compute_chunk(av1, bv1);
+      }
+    }
   }
 
-  float* slab = a.slab + (int64_t)split * a.K * a.N;
 #pragma unroll
   for (int i = 0; i < WG_TM; ++i)
 #pragma unroll
@@ -297,25 +350,99 @@ __global__ __launch_bounds__(256) void wn_wgrad_kernel(WnWgradArgs a, int nkb, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = k0 + 32 * i + wn_drow(r, h);
-        if (k < a.K && n < a.N) slab[(int64_t)k * a.N + n] = acc[i][j][r];
+        if (k < a.K && n < a.N) a.out[(int64_t)k * a.out_ld + n] = acc[i][j][r];
       }
     }
-  if (a.slab_bias && kb == 0) {
+  if (a.bias) {
 #pragma unroll
     for (int j = 0; j < WG_TN; ++j) {
       const float tot = bsum[j] + __shfl_xor(bsum[j], 32);
       const int n = n0 + 32 * j + tl;
-      if (h == 0 && n < a.N) a.slab_bias[(int64_t)split * a.N + n] = tot;
+      if (h == 0 && n < a.N) a.bias[n] = tot;
     }
   }
 }
 
+__global__ __launch_bounds__(256, 2) void wn_wgrad_kernel(WnWgradArgs a, int nkb, int nnb) {
+  const int wave = threadIdx.x >> 6;
+  const int nsplit = a.B * a.splits_per_b;
+  const int split = blockIdx.x * 4 + wave;
+  if (split >= nsplit) return;                         // wave-uniform
+  const int kb = blockIdx.y / nnb, nb = blockIdx.y % nnb;
+  const int sp = split % a.splits_per_b;
+  int len = (a.T + a.splits_per_b - 1) / a.splits_per_b;
+  len = (len + 1) & ~1;
+  WnWgUnit u;
+  u.x = a.x; u.ldx = a.ldx; u.K = a.K; u.shift = a.shift; u.g = a.g; u.ldg = a.ldg; u.N = a.N;
+  u.T = a.T; u.b = split / a.splits_per_b; u.r0 = sp * len; u.r1 = min(a.T, u.r0 + len);
+  u.k0 = kb * 32 * WG_TM; u.n0 = nb * 32 * WG_TN;
+  u.out = a.slab + (int64_t)split * a.K * a.N; u.out_ld = a.N;
+  u.bias = (a.slab_bias && kb == 0) ? a.slab_bias + (int64_t)split * a.N : nullptr;
+  wn_wgrad_body(u);
+}
+
+// Batched form: a table of jobs (one per K-block x N-block of some dW), every job split over
+// time; partial results go to slab[split][P] laid out exactly like the flat gradient buffer.
+__global__ __launch_bounds__(256, 2) void wn_wgrad_batched_kernel(const WnWgJob* jobs, float* ws, float* slab,
+                                                                  int64_t P, int B, int T, int splits_per_b) {
+  const int wave = threadIdx.x >> 6;
+  const int nsplit = B * splits_per_b;
+  const int split = blockIdx.x * 4 + wave;
+  if (split >= nsplit) return;                         // wave-uniform
+  const WnWgJob j = jobs[blockIdx.y];
+  const int sp = split % splits_per_b;
+  int len = (T + splits_per_b - 1) / splits_per_b;
+  len = (len + 1) & ~1;
+  WnWgUnit u;
+  u.x = ws + j.x_off; u.ldx = j.ldx; u.K = j.K; u.shift = j.shift; u.g = ws + j.g_off; u.ldg = j.ldg; u.N = j.N;
+  u.T = T; u.b = split / splits_per_b; u.r0 = sp * len; u.r1 = min(T, u.r0 + len);
+  u.k0 = j.k0; u.n0 = j.n0;
+  float* row = slab + (int64_t)split * P;
+  u.out = row + j.out_off; u.out_ld = j.N;
+  u.bias = j.bias_off >= 0 ? row + j.bias_off : nullptr;
+  wn_wgrad_body(u);
+}
+
+int wn_launch_wgrad_batched(const WnWgJob* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
+                            int splits_per_b, hipStream_t s) {
+  if (njobs <= 0) return WN_OK;
+  const int nsplit = B * splits_per_b;
+  hipLaunchKernelGGL(wn_wgrad_batched_kernel, dim3((nsplit + 3) / 4, njobs), dim3(256), 0, s, d_jobs, ws, slab, P, B,
+                     T, splits_per_b);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// grads[off + i] = sum_s slab[s][off + i] over the tensors of a table
+__global__ void wn_reduce_table_kernel(const float* slab, int nsplit, int64_t P, float* out,
+                                       const WnTensorDesc* table) {
+  const WnTensorDesc d = table[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += slab[(int64_t)s * P + d.off + i];
+    out[d.off + i] = acc;
+  }
+}
+
+int wn_launch_reduce_table(const float* slab, int nsplit, int64_t P, float* out, const WnTensorDesc* d_table,
+                           int n, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_reduce_table_kernel, dim3(64, n), dim3(256), 0, s, slab, nsplit, P, out, d_table);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+int wn_wgrad_tile_k() { return 32 * WG_TM; }
+int wn_wgrad_tile_n() { return 32 * WG_TN; }
+
 int wn_wgrad_choose_splits(int B, int T, int K, int N) {
   const int jobs = ((K + 32 * WG_TM - 1) / (32 * WG_TM)) * ((N + 32 * WG_TN - 1) / (32 * WG_TN));
-  // aim at ~2 waves per SIMD over the chip (2048 waves), at least 64 rows per split
-  int want = (2048 + jobs - 1) / jobs;
+  // aim at one wave per SIMD over the chip (1024 waves), at least 256 rows per split: every
+  // split costs a K x N partial slab that has to be written and reduced
+  int want = (1024 + jobs - 1) / jobs;
   int per_b = (want + B - 1) / B;
-  const int max_per_b = (T + 63) / 64;
+  const int max_per_b = (T + 255) / 256;
   if (per_b > max_per_b) per_b = max_per_b;
   if (per_b < 1) per_b = 1;
   return per_b;
@@ -332,12 +459,28 @@ int wn_launch_wgrad(const WnWgradArgs& a, hipStream_t s) {
   return WN_OK;
 }
 
-__global__ void wn_reduce_kernel(WnReduceArgs a) {
+// Stage A: fold groups of WN_RED_GROUP splits in place (row g*GROUP of the slab receives the
+// group's sum; only this thread touches column i of those rows).  Stage B: sum the group rows
+// in a fixed order and scatter to the gradient tensor.  Both are deterministic.
+#define WN_RED_GROUP 16
+__global__ void wn_reduce_stageA_kernel(float* slab, int nsplit, int64_t total) {
+  const int g = blockIdx.y;
+  const int s0 = g * WN_RED_GROUP;
+  const int s1 = min(nsplit, s0 + WN_RED_GROUP);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = s0; s < s1; ++s) acc += slab[(int64_t)s * total + i];
+    slab[(int64_t)s0 * total + i] = acc;
+  }
+}
+
+__global__ void wn_reduce_kernel(WnReduceArgs a, int stride) {
   const int64_t total = (int64_t)a.K * a.N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) acc += a.slab[(int64_t)s * total + i];
+    for (int s = 0; s < a.nsplit; s += stride) acc += a.slab[(int64_t)s * total + i];
     const int k = (int)(i / a.N), n = (int)(i % a.N);
     float* dst = a.out + (int64_t)(k / a.seg_len) * a.seg_stride + (int64_t)(k % a.seg_len) * a.N + n;
     for (int r = 0; r < a.replicate; ++r) {
@@ -352,7 +495,14 @@ int wn_launch_reduce(const WnReduceArgs& a, hipStream_t s) {
   if (total <= 0) return WN_OK;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wn_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+  int stride = 1;
+  if (a.nsplit > 2 * WN_RED_GROUP) {
+    const int groups = (a.nsplit + WN_RED_GROUP - 1) / WN_RED_GROUP;
+    hipLaunchKernelGGL(wn_reduce_stageA_kernel, dim3(blocks, groups), dim3(256), 0, s,
+                       const_cast<float*>(a.slab), a.nsplit, total);
+    stride = WN_RED_GROUP;
+  }
+  hipLaunchKernelGGL(wn_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, stride);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

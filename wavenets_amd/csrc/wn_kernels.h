@@ -2,6 +2,8 @@
 #pragma once
 #include "wn_common.h"
 
+struct WnTensorDesc { int64_t off; int64_t len; };
+
 // ---------------------------------------------------------------- weight preparation
 // One descriptor = one dense matrix copied into a fragment-major image (wn_common.h).
 // Offsets are in floats relative to the base pointers given at launch, so that a table
@@ -67,6 +69,18 @@ struct WnWgradArgs {
 };
 int wn_wgrad_choose_splits(int B, int T, int K, int N);
 int wn_launch_wgrad(const WnWgradArgs& a, hipStream_t s);
+// batched form: one job per (K-block, N-block) of some dW; offsets are floats relative to the
+// workspace base (operands) and to a slab row / the flat gradient buffer (outputs)
+struct WnWgJob {
+  int64_t x_off, g_off, out_off, bias_off;   // bias_off < 0: no bias sum from this job
+  int32_t ldx, ldg, K, N, shift, k0, n0, pad_;
+};
+int wn_wgrad_tile_k();
+int wn_wgrad_tile_n();
+int wn_launch_wgrad_batched(const WnWgJob* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
+                            int splits_per_b, hipStream_t s);
+int wn_launch_reduce_table(const float* slab, int nsplit, int64_t P, float* out, const WnTensorDesc* d_table,
+                           int n, hipStream_t s);
 // out[(k / seg_len) * seg_stride + (k % seg_len) * N + n] (+)= sum_s slab[s][k][n]
 struct WnReduceArgs {
   const float* slab; int32_t nsplit; int32_t K; int32_t N;
@@ -123,7 +137,6 @@ int wn_launch_sample_rand(const float* pred, int64_t rows, int C, int M, int bit
                           uint64_t seed, uint64_t offset, float* out, hipStream_t s);
 
 // ---------------------------------------------------------------- optimizer
-struct WnTensorDesc { int64_t off; int64_t len; };
 int wn_launch_sumsq(const float* g, const WnTensorDesc* d_table, int n, float* norms2, hipStream_t s);
 int wn_launch_axpy_table(float* y, const float* x, const WnTensorDesc* d_table, int n, float coef,
                          hipStream_t s);

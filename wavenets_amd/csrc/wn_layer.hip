@@ -33,46 +33,95 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
   const bool tin = t < a.T;
   const int64_t row = (int64_t)b * a.T + (tin ? t : 0);
 
-  // ---- u accumulators start at the bias (+ per-utterance conditioning bias) ----
+  // ---- every activation load of the tile is issued up front (HBM latency), KS taps ----
+  //      loads are unconditional from a clamped row; the causal zero padding is applied where the
+  //      value is consumed, so that no load is followed by a wait
+  f32x4 xq[KS][QR];
+  bool xvalid[KS];
+#pragma unroll
+  for (int tap = 0; tap < KS; ++tap) {
+    const int ts = t - (KS - 1 - tap) * a.dilation;
+    xvalid[tap] = tin && ts >= 0;
+    const float* xrow = a.x + ((int64_t)b * a.T + (xvalid[tap] ? ts : 0)) * R + 4 * h;
+#pragma unroll
+    for (int q = 0; q < QR; ++q) xq[tap][q] = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
+  }
+
+  // ---- u accumulators start at the bias (+ per-utterance conditioning bias); all loads are
+  //      issued back to back straight into the accumulator registers ----
   f32x16 u[JU];
 #pragma unroll
   for (int j = 0; j < JU; ++j)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
-      const int n0 = 32 * j + 8 * rq + 4 * h;
-      f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias_d + n0);
-      if (a.cb) {
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(a.cb + (int64_t)b * 2 * D + n0);
-        bv.x += cv.x; bv.y += cv.y; bv.z += cv.z; bv.w += cv.w;
-      }
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias_d + 32 * j + 8 * rq + 4 * h);
       u[j][4 * rq + 0] = bv.x; u[j][4 * rq + 1] = bv.y;
       u[j][4 * rq + 2] = bv.z; u[j][4 * rq + 3] = bv.w;
     }
-
-  // ---- dilated causal conv: KS taps, each a K = R contraction ----
-  f32x4 xres[QR];                  // x[t] in D-tile layout (last tap), kept for the residual
-  const f32x4* frd = reinterpret_cast<const f32x4*>(a.frag_d) + lane;
+  if (a.cb) {   // wave-uniform
+    const float* cbp = a.cb + (int64_t)b * 2 * D + 4 * h;
+    f32x4 cv[JU][4];
 #pragma unroll
-  for (int tap = 0; tap < KS; ++tap) {
-    const int ts = t - (KS - 1 - tap) * a.dilation;
-    const bool valid = tin && ts >= 0;
-    const float* xrow = a.x + ((int64_t)b * a.T + (valid ? ts : 0)) * R + 4 * h;
-    const f32x4* fr = frd + (int64_t)tap * QR * JU * 64;
+    for (int j = 0; j < JU; ++j)
 #pragma unroll
-    for (int q = 0; q < QR; ++q) {
-      f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-      if (valid) xv = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
-      if (tap == KS - 1) xres[q] = xv;
+      for (int rq = 0; rq < 4; ++rq) cv[j][rq] = *reinterpret_cast<const f32x4*>(cbp + 32 * j + 8 * rq);
 #pragma unroll
-      for (int j = 0; j < JU; ++j) {
-        const f32x4 av = fr[(q * JU + j) * 64];
-        u[j] = wn_mfma(av.x, xv.x, u[j]);
-        u[j] = wn_mfma(av.y, xv.y, u[j]);
-        u[j] = wn_mfma(av.z, xv.z, u[j]);
-        u[j] = wn_mfma(av.w, xv.w, u[j]);
+    for (int j = 0; j < JU; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u[j][4 * rq + 0] += cv[j][rq].x; u[j][4 * rq + 1] += cv[j][rq].y;
+        u[j][4 * rq + 2] += cv[j][rq].z; u[j][4 * rq + 3] += cv[j][rq].w;
       }
-    }
   }
+
+  // ---- dilated causal conv: KS*QR steps, weight fragments streamed PD steps ahead through a
+  //      register ring (the compiler otherwise parks every load right in front of its MFMAs) ----
+  constexpr int PD = 2;
+  constexpr int NS1 = KS * QR;
+  const f32x4* frd = reinterpret_cast<const f32x4*>(a.frag_d) + lane;   // step s -> blocks (s*JU + j)
+  f32x4 ring[PD + 1][JU];
+  wn_static_for<PD>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    if constexpr (st < NS1) {
+#pragma unroll
+      for (int j = 0; j < JU; ++j) ring[st % (PD + 1)][j] = frd[(st * JU + j) * 64];
+    }
+  });
+  wn_static_for<NS1>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    constexpr int tap = st / QR, q = st % QR;
+    if constexpr (st + PD < NS1) {
+#pragma unroll
+      for (int j = 0; j < JU; ++j) ring[(st + PD) % (PD + 1)][j] = frd[((st + PD) * JU + j) * 64];
+    }
+    // keep the prefetch where it was issued: the scheduler otherwise sinks it next to its use
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 xv = xq[tap][q];
+    if (!xvalid[tap]) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < JU; ++j) {
+      const f32x4 av = ring[st % (PD + 1)][j];
+      u[j] = wn_mfma(av.x, xv.x, u[j]);
+      u[j] = wn_mfma(av.y, xv.y, u[j]);
+      u[j] = wn_mfma(av.z, xv.z, u[j]);
+      u[j] = wn_mfma(av.w, xv.w, u[j]);
+    }
+  });
+
+  // ---- 1x1 conv weight fragments: start streaming before the (VALU-heavy) gate ----
+  constexpr int NS2 = D32 * 4;
+  constexpr int PD2 = (R32 <= 2) ? 4 : 2;
+  const f32x4* frr = reinterpret_cast<const f32x4*>(a.frag_r) + lane;
+  f32x4 ring2[PD2 + 1][R32];
+  wn_static_for<PD2>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    if constexpr (st < NS2) {
+#pragma unroll
+      for (int j = 0; j < R32; ++j) ring2[st % (PD2 + 1)][j] = frr[(st * R32 + j) * 64];
+    }
+  });
+
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- gate: z = tanh(filter) * sigmoid(gate), in place in the filter tiles ----
 #pragma unroll
@@ -80,10 +129,10 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       f32x4 av, gv, zv;
-      av.x = tanhf(u[j][4 * rq + 0]); gv.x = wn_sigmoid(u[j + D32][4 * rq + 0]);
-      av.y = tanhf(u[j][4 * rq + 1]); gv.y = wn_sigmoid(u[j + D32][4 * rq + 1]);
-      av.z = tanhf(u[j][4 * rq + 2]); gv.z = wn_sigmoid(u[j + D32][4 * rq + 2]);
-      av.w = tanhf(u[j][4 * rq + 3]); gv.w = wn_sigmoid(u[j + D32][4 * rq + 3]);
+      av.x = wn_tanh_fast(u[j][4 * rq + 0]); gv.x = wn_sigmoid_fast(u[j + D32][4 * rq + 0]);
+      av.y = wn_tanh_fast(u[j][4 * rq + 1]); gv.y = wn_sigmoid_fast(u[j + D32][4 * rq + 1]);
+      av.z = wn_tanh_fast(u[j][4 * rq + 2]); gv.z = wn_sigmoid_fast(u[j + D32][4 * rq + 2]);
+      av.w = wn_tanh_fast(u[j][4 * rq + 3]); gv.w = wn_sigmoid_fast(u[j + D32][4 * rq + 3]);
       zv.x = av.x * gv.x; zv.y = av.y * gv.y; zv.z = av.z * gv.z; zv.w = av.w * gv.w;
       u[j][4 * rq + 0] = zv.x; u[j][4 * rq + 1] = zv.y;
       u[j][4 * rq + 2] = zv.z; u[j][4 * rq + 3] = zv.w;
@@ -108,22 +157,23 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
       o[j][4 * rq + 0] = bv.x; o[j][4 * rq + 1] = bv.y;
       o[j][4 * rq + 2] = bv.z; o[j][4 * rq + 3] = bv.w;
     }
-  const f32x4* frr = reinterpret_cast<const f32x4*>(a.frag_r) + lane;
+  wn_static_for<NS2>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    constexpr int jz = st / 4, qq = st % 4;
+    if constexpr (st + PD2 < NS2) {
 #pragma unroll
-  for (int jz = 0; jz < D32; ++jz) {
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int q = jz * 4 + qq;
-#pragma unroll
-      for (int j = 0; j < R32; ++j) {
-        const f32x4 av = frr[(q * R32 + j) * 64];
-        o[j] = wn_mfma(av.x, u[jz][4 * qq + 0], o[j]);
-        o[j] = wn_mfma(av.y, u[jz][4 * qq + 1], o[j]);
-        o[j] = wn_mfma(av.z, u[jz][4 * qq + 2], o[j]);
-        o[j] = wn_mfma(av.w, u[jz][4 * qq + 3], o[j]);
-      }
+      for (int j = 0; j < R32; ++j) ring2[(st + PD2) % (PD2 + 1)][j] = frr[((st + PD2) * R32 + j) * 64];
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < R32; ++j) {
+      const f32x4 av = ring2[st % (PD2 + 1)][j];
+      o[j] = wn_mfma(av.x, u[jz][4 * qq + 0], o[j]);
+      o[j] = wn_mfma(av.y, u[jz][4 * qq + 1], o[j]);
+      o[j] = wn_mfma(av.z, u[jz][4 * qq + 2], o[j]);
+      o[j] = wn_mfma(av.w, u[jz][4 * qq + 3], o[j]);
+    }
+  });
 
   if (!tin) return;
 #pragma unroll
@@ -136,7 +186,7 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
       ov.z = o[j][4 * rq + 2]; ov.w = o[j][4 * rq + 3];
       if (a.o_out) *reinterpret_cast<f32x4*>(a.o_out + row * R + n0) = ov;
       if (a.residual) {
-        const f32x4 xr = a.res ? *reinterpret_cast<const f32x4*>(a.res + row * R + n0) : xres[j * 4 + rq];
+        const f32x4 xr = a.res ? *reinterpret_cast<const f32x4*>(a.res + row * R + n0) : xq[KS - 1][j * 4 + rq];
         ov.x += xr.x; ov.y += xr.y; ov.z += xr.z; ov.w += xr.w;
       }
       *reinterpret_cast<f32x4*>(a.x_out + row * R + n0) = ov;

@@ -65,6 +65,10 @@ struct wn_plan {
   WnTensorDesc* d_tdesc = nullptr;
   WnTensorDesc* d_kdesc = nullptr;
   bool fused_ok = false;
+  // batched weight-gradient job table (device), valid for one (B, T) workspace layout
+  WnWgJob* d_jobs = nullptr;
+  WnTensorDesc* d_cov = nullptr;
+  int njobs = 0, ncov = 0, jobs_B = 0, jobs_T = 0, jobs_splits = 0;
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   int prof_used = 0;
@@ -172,6 +176,8 @@ struct WsLayout {
   int64_t g_o;                          // [rows][R]
   int64_t g_p;                          // [rows][D] (depth > 1)
   int64_t slab, slab_floats;
+  std::vector<int64_t> GU, GH, GO, GF;  // deferred-wgrad mode: per-block g_u, g_h (N+1), g_o; per-final g
+  int64_t bslab; int bsplits;           // batched slab [B*bsplits][nparams]
   int64_t sum_scratch;
   std::vector<int64_t> M;               // mapping activations [B][w]
   int64_t cb;                           // [N][B][2D]
@@ -182,6 +188,24 @@ struct WsLayout {
 int64_t slab_need(int B, int T, int K, int N) {
   const int sp = wn_wgrad_choose_splits(B, T, K, N);
   return (int64_t)B * sp * ((int64_t)K * N + N);
+}
+
+// The batched weight-gradient path needs depth-1 blocks (every dW operand is then a whole saved
+// tensor); deeper stacks use the per-call path.
+bool deferred_wgrad(const wn_plan* p) { return p->LPB == 1; }
+
+int jobs_for(int K, int N) {
+  return ((K + wn_wgrad_tile_k() - 1) / wn_wgrad_tile_k()) * ((N + wn_wgrad_tile_n() - 1) / wn_wgrad_tile_n());
+}
+
+int count_jobs(const wn_plan* p) {
+  int n = p->KS * jobs_for(1, p->R);
+  for (const BlockInfo& b : p->blocks) {
+    n += p->KS * jobs_for(p->R, 2 * p->D) + jobs_for(p->D, p->R);
+    if (b.has_skip && p->c.use_skip) n += jobs_for(p->D, p->S);
+  }
+  for (const ConvInfo& c : p->finals) n += jobs_for(c.cin, c.cout);
+  return n;
 }
 
 WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
@@ -249,7 +273,21 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     if (p->c.cond_inputs > 0) need = std::max(need, slab_need(1, B, p->Cc, 2 * p->D));
     L.slab_floats = need;
     L.slab = cv.take(need);
+    L.bslab = 0; L.bsplits = 0;
+    if (deferred_wgrad(p)) {
+      for (int b = 0; b < p->N; ++b) L.GU.push_back(cv.take(rows * 2 * p->D));
+      for (int b = 0; b <= p->N; ++b) L.GH.push_back(cv.take(rows * p->R));
+      if (p->S == 0) for (int b = 0; b < p->N; ++b) L.GO.push_back(cv.take(rows * p->R));
+      for (size_t i = 0; i < p->finals.size(); ++i) L.GF.push_back(cv.take(rows * p->finals[i].cout));
+      const int nj = count_jobs(p);
+      int sp = (int)((5000 + (int64_t)nj * B - 1) / ((int64_t)nj * B));
+      const int maxsp = std::max(1, (T + 255) / 256);
+      sp = std::max(1, std::min(sp, maxsp));
+      L.bsplits = sp;
+      L.bslab = cv.take((int64_t)B * sp * p->nparams);
+    }
   } else {
+    L.bslab = 0; L.bsplits = 0;
     L.g_a = L.g_b = L.g_skipsum = L.g_h0 = L.g_h1 = L.g_o = L.g_p = L.slab = 0;
     L.slab_floats = 0;
   }
@@ -303,6 +341,11 @@ int wgrad(const float* x, int ldx, int K, int shift, const float* g, int ldg, in
   a.slab_bias = (db || per_batch) ? slab + (int64_t)nsplit * K * N : nullptr;
   int rc = wn_launch_wgrad(a, s);
   if (rc) return rc;
+  // per-utterance sums first: the reduces below fold the slabs in place
+  if (per_batch) {
+    rc = wn_launch_batch_reduce(a.slab_bias, B, a.splits_per_b, N, per_batch, s);
+    if (rc) return rc;
+  }
   if (dW) {
     WnReduceArgs r;
     memset(&r, 0, sizeof(r));
@@ -319,7 +362,6 @@ int wgrad(const float* x, int ldx, int K, int shift, const float* g, int ldg, in
     rc = wn_launch_reduce(r, s);
     if (rc) return rc;
   }
-  if (per_batch) rc = wn_launch_batch_reduce(a.slab_bias, B, a.splits_per_b, N, per_batch, s);
   return rc;
 }
 
@@ -415,6 +457,7 @@ struct BlockGrads {
   float* dWr; float* dbr; float* dWs; float* dbs; float* dWc; float* dbc;
   float* dcb;               // [B][2D] per-utterance sums of g_u (model conditioning) or null
   float* slab;
+  bool defer;               // weight gradients are computed later by the batched job table
 };
 
 int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, hipStream_t s) {
@@ -447,14 +490,20 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     if (rc) return rc;
   }
   // conv1 / conv_skip weight gradients
-  if (g_o) {
+  if (g.defer) {
+    // batched later; only the per-utterance column sums of g_u are needed now (conditioning)
+    if (g.dcb) {
+      rc = wn_launch_colsum_per_batch(g.g_u, k.B, k.T, 2 * k.D, g.dcb, s);
+      if (rc) return rc;
+    }
+  } else if (g_o) {
     rc = wgrad(f.Z, f.ldz, k.D, 0, g_o, k.R, k.R, k.B, k.T, g.dWr, g.dbr, nullptr, g.slab, s);
   } else {
     rc = wn_launch_fill(g.dWr, 0.f, (int64_t)k.D * k.R, s);
     if (!rc) rc = wn_launch_fill(g.dbr, 0.f, k.R, s);
   }
   if (rc) return rc;
-  if (k.S > 0 && g.dWs) {
+  if (!g.defer && k.S > 0 && g.dWs) {
     if (g.g_skip) {
       rc = wgrad(f.Z, f.ldz, k.D, 0, g.g_skip, k.S, k.S, k.B, k.T, g.dWs, g.dbs, nullptr, g.slab, s);
     } else {
@@ -478,7 +527,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
   for (int i = li; i >= 0; --i) {
     const float* hin = (i > 0) ? f.P[i - 1] : f.x;
     const int hc = (i > 0) ? k.D : k.Cin;
-    for (int t = 0; t < k.KS; ++t) {
+    for (int t = 0; t < k.KS && !g.defer; ++t) {
       const bool last_tap = (t == k.KS - 1);
       rc = wgrad(hin, hc, hc, (k.KS - 1 - t) * k.dil[i], gcur, gc, gc, k.B, k.T,
                  g.dWd[i] + (int64_t)t * hc * gc, last_tap ? g.dbd[i] : nullptr,
@@ -619,6 +668,8 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_tdesc) (void)hipFree(p->d_tdesc);
   if (p->d_kdesc) (void)hipFree(p->d_kdesc);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+  if (p->d_jobs) (void)hipFree(p->d_jobs);
+  if (p->d_cov) (void)hipFree(p->d_cov);
   delete p;
 }
 
@@ -838,6 +889,67 @@ int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float
   return wn_launch_sum(ws + L.loss_rows, rows, gscale, loss_out, ws + L.sum_scratch, s);
 }
 
+// ---- batched weight-gradient job table for one (B, T) layout ----
+void add_jobs(std::vector<WnWgJob>& jobs, int64_t x_off, int ldx, int K, int shift, int64_t g_off, int ldg, int N,
+              int64_t out_off, int64_t bias_off) {
+  const int tk = wn_wgrad_tile_k(), tn = wn_wgrad_tile_n();
+  for (int k0 = 0; k0 < K; k0 += tk)
+    for (int n0 = 0; n0 < N; n0 += tn) {
+      WnWgJob j;
+      memset(&j, 0, sizeof(j));
+      j.x_off = x_off; j.g_off = g_off; j.out_off = out_off; j.bias_off = (k0 == 0) ? bias_off : -1;
+      j.ldx = ldx; j.ldg = ldg; j.K = K; j.N = N; j.shift = shift; j.k0 = k0; j.n0 = n0;
+      jobs.push_back(j);
+    }
+}
+
+int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
+  if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits) return WN_OK;
+  std::vector<WnWgJob> jobs;
+  std::vector<WnTensorDesc> cov;
+  auto cover = [&](int t) { WnTensorDesc d; d.off = p->tensors[t].off; d.len = p->tensors[t].len; cov.push_back(d); };
+  // input causal conv: x = inputs (B,T,1), g = d loss / d H[0]
+  for (int t = 0; t < p->KS; ++t)
+    add_jobs(jobs, L.probs, 1, 1, p->KS - 1 - t, L.GH[0], p->R, p->R,
+             p->tensors[p->causal.kernel_t].off + (int64_t)t * p->R,
+             t == p->KS - 1 ? p->tensors[p->causal.bias_t].off : -1);
+  cover(p->causal.kernel_t); cover(p->causal.bias_t);
+  for (int b = 0; b < p->N; ++b) {
+    const BlockInfo& bi = p->blocks[b];
+    const ConvInfo& c = bi.dil[0];
+    for (int t = 0; t < p->KS; ++t)
+      add_jobs(jobs, L.H[b], p->R, p->R, (p->KS - 1 - t) * c.dil, L.GU[b], 2 * p->D, 2 * p->D,
+               p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D,
+               t == p->KS - 1 ? p->tensors[c.bias_t].off : -1);
+    cover(c.kernel_t); cover(c.bias_t);
+    const int64_t zoff = L.Z + (int64_t)b * p->Dp;
+    add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, p->S == 0 ? L.GO[b] : L.GH[b + 1], p->R, p->R,
+             p->tensors[bi.conv1.kernel_t].off, p->tensors[bi.conv1.bias_t].off);
+    cover(bi.conv1.kernel_t); cover(bi.conv1.bias_t);
+    if (bi.has_skip && p->c.use_skip) {
+      add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, L.g_skipsum, p->S, p->S,
+               p->tensors[bi.conv_skip.kernel_t].off, p->tensors[bi.conv_skip.bias_t].off);
+      cover(bi.conv_skip.kernel_t); cover(bi.conv_skip.bias_t);
+    }
+  }
+  for (size_t i = 0; i < p->finals.size(); ++i) {
+    const ConvInfo& c = p->finals[i];
+    const int64_t xin = (i == 0) ? (p->c.use_skip ? L.skipsum : L.H[p->N]) : L.HA[i - 1];
+    add_jobs(jobs, xin, c.cin, c.cin, 0, L.GF[i], c.cout, c.cout, p->tensors[c.kernel_t].off,
+             p->tensors[c.bias_t].off);
+    cover(c.kernel_t); cover(c.bias_t);
+  }
+  if (p->d_jobs) { (void)hipFree(p->d_jobs); p->d_jobs = nullptr; }
+  if (p->d_cov) { (void)hipFree(p->d_cov); p->d_cov = nullptr; }
+  WN_HIP_CHECK(hipMalloc((void**)&p->d_jobs, jobs.size() * sizeof(WnWgJob)));
+  WN_HIP_CHECK(hipMemcpy(p->d_jobs, jobs.data(), jobs.size() * sizeof(WnWgJob), hipMemcpyHostToDevice));
+  WN_HIP_CHECK(hipMalloc((void**)&p->d_cov, cov.size() * sizeof(WnTensorDesc)));
+  WN_HIP_CHECK(hipMemcpy(p->d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+  p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
+  p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits;
+  return WN_OK;
+}
+
 }  // namespace
 
 extern "C" int wn_forward(wn_plan* p, const float* params, const float* x, const float* cond, int32_t B,
@@ -908,6 +1020,88 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   const float* fragbase = ws + L.frag;
   float* slab = ws + L.slab;
 
+  const bool defer = deferred_wgrad(p);
+  const float* mlast = nullptr;
+  if (p->c.cond_inputs > 0) {
+    mlast = p->mapping.empty() ? cond : ws + L.M.back();
+    rc = wn_launch_fill(ws + L.g_m0, 0.f, (int64_t)B * p->Cc, s);
+    if (rc) return rc;
+  }
+  auto cond_block_bwd = [&](const BlockInfo& bi) -> int {
+    // conv_cond on the time-invariant mapped condition: dW_c = m^T dcb, db_c = sum_b dcb,
+    // g_m += dcb W_c^T
+    const ConvInfo& c = bi.conv_cond;
+    int r = wgrad(mlast, p->Cc, p->Cc, 0, ws + L.dcb, 2 * p->D, 2 * p->D, 1, B, grads + p->tensors[c.kernel_t].off,
+                  grads + p->tensors[c.bias_t].off, nullptr, slab, s);
+    if (r) return r;
+    return Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.dcb, 2 * p->D, 2 * p->D, 0, fragbase + c.fragB)
+        .addc(ws + L.g_m0, p->Cc).run(ws + L.g_m0, p->Cc, s);
+  };
+
+  if (defer) {
+    // ================= data gradients now, every weight gradient in one batched launch =================
+    rc = ensure_jobs(p, L, B, T);
+    if (rc) return rc;
+    // the loss stage wrote d loss / d logits to g_a: the last final layer's g lives in GF.back()
+    WN_HIP_CHECK(hipMemcpyAsync(ws + L.GF.back(), ws + L.g_a, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    float* head_out = p->c.use_skip ? ws + L.g_skipsum : ws + L.GH[p->N];
+    for (int i = (int)p->finals.size() - 1; i >= 0; --i) {
+      const ConvInfo& c = p->finals[i];
+      Gemm gm(B, T, c.cin, ceil32(c.cin));
+      gm.seg(ws + L.GF[i], c.cout, c.cout, 0, fragbase + c.fragB);
+      float* dst = (i == 0) ? head_out : ws + L.GF[i - 1];
+      if (i > 0) gm.dact(ws + L.HA[i - 1], c.cin, p->c.activation);
+      rc = gm.run(dst, c.cin, s);
+      if (rc) return rc;
+    }
+    const float* g_skip = p->c.use_skip ? ws + L.g_skipsum : nullptr;
+    if (p->c.use_skip) {
+      rc = wn_launch_fill(ws + L.GH[p->N], 0.f, rows * p->R, s);   // nothing flows into the last block output
+      if (rc) return rc;
+    }
+    for (int b = p->N - 1; b >= 0; --b) {
+      BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
+      const BlockInfo& bi = p->blocks[b];
+      BlockBufs f;
+      memset(&f, 0, sizeof(f));
+      f.x = ws + L.H[b];
+      f.AG = ws + L.AG[b];
+      f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+      BlockGrads bg;
+      memset(&bg, 0, sizeof(bg));
+      bg.defer = true;
+      // the last block's output gradient is identically zero when the head reads the skip sum
+      bg.g_xout = (p->c.use_skip && b == p->N - 1) ? nullptr : ws + L.GH[b + 1];
+      bg.g_skip = g_skip;
+      bg.g_o_tmp = p->S == 0 ? ws + L.GO[b] : nullptr;
+      bg.g_u = ws + L.GU[b];
+      bg.g_x = ws + L.GH[b];
+      bg.dcb = bi.has_cond ? ws + L.dcb : nullptr;
+      bg.slab = slab;
+      rc = block_backward(k, f, bg, s);
+      if (rc) return rc;
+      if (p->S == 0 && bg.g_xout == nullptr && g_skip) {
+        // g_o == g_skip for this block: the job table reads GO[b]
+        WN_HIP_CHECK(hipMemcpyAsync(ws + L.GO[b], g_skip, rows * p->R * sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+      if (bi.has_cond) {
+        rc = cond_block_bwd(bi);
+        if (rc) return rc;
+      }
+    }
+    rc = wn_launch_wgrad_batched(p->d_jobs, p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
+    if (rc) return rc;
+    rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov, p->ncov, s);
+    if (rc) return rc;
+    if (!p->c.use_skip && p->S > 0) {
+      for (const BlockInfo& bi : p->blocks) {     // unused skip convs: zero gradients
+        rc = wn_launch_fill(grads + p->tensors[bi.conv_skip.kernel_t].off, 0.f, p->tensors[bi.conv_skip.kernel_t].len, s);
+        if (!rc) rc = wn_launch_fill(grads + p->tensors[bi.conv_skip.bias_t].off, 0.f, p->tensors[bi.conv_skip.bias_t].len, s);
+        if (rc) return rc;
+      }
+    }
+  } else {
+  // ================= per-call weight gradients (blocks with depth > 1) =================
   // ---- head backward ----
   const float* g = ws + L.g_a;          // d loss / d logits
   float* gnext = ws + L.g_b;
@@ -929,12 +1123,6 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   const float* g_skip = p->c.use_skip ? ws + L.g_skipsum : nullptr;
   const float* g_xout = p->c.use_skip ? nullptr : ws + L.g_skipsum;   // head fed by the last block output
   float* ghbuf[2] = {ws + L.g_h0, ws + L.g_h1};
-  if (p->c.cond_inputs > 0) {
-    rc = wn_launch_fill(ws + L.g_m0, 0.f, (int64_t)B * p->Cc, s);
-    if (rc) return rc;
-  }
-  const float* mlast = nullptr;
-  if (p->c.cond_inputs > 0) mlast = p->mapping.empty() ? cond : ws + L.M.back();
   for (int b = p->N - 1; b >= 0; --b) {
     BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
     const BlockInfo& bi = p->blocks[b];
@@ -959,14 +1147,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     rc = block_backward(k, f, bg, s);
     if (rc) return rc;
     if (bi.has_cond) {
-      // conv_cond on the time-invariant mapped condition: dW_c = m^T dcb, db_c = sum_b dcb,
-      // g_m += dcb W_c^T
-      const ConvInfo& c = bi.conv_cond;
-      rc = wgrad(mlast, p->Cc, p->Cc, 0, ws + L.dcb, 2 * p->D, 2 * p->D, 1, B, grads + p->tensors[c.kernel_t].off,
-                 grads + p->tensors[c.bias_t].off, nullptr, slab, s);
-      if (rc) return rc;
-      rc = Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.dcb, 2 * p->D, 2 * p->D, 0, fragbase + c.fragB)
-               .addc(ws + L.g_m0, p->Cc).run(ws + L.g_m0, p->Cc, s);
+      rc = cond_block_bwd(bi);
       if (rc) return rc;
     }
     g_xout = bg.g_x;
@@ -977,6 +1158,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
                grads + p->tensors[p->causal.kernel_t].off + (int64_t)t * p->R,
                (t == p->KS - 1) ? grads + p->tensors[p->causal.bias_t].off : nullptr, nullptr, slab, s);
     if (rc) return rc;
+  }
   }
   // ---- mapping Dense stack backward ----
   if (p->c.cond_inputs > 0) {
