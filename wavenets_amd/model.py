@@ -365,12 +365,8 @@ class WaveNet(torch.nn.Module):
       raise RuntimeError('compile(optimizer=...) first')
     want_metric = len(self._metrics_from_compilation) > 0
     loss, pred, y_true = self.loss_and_grads(data, want_pred=want_metric)
-    world = self._world()
-    if world > 1:
-      import torch.distributed as dist
-      dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM)
-      dist.all_reduce(loss, op=dist.ReduceOp.SUM)
-      loss[1] /= world              # every replica added the same reg_loss / n_replicas
+    from . import dp
+    dp.allreduce_gradients(self.flat_grads, loss)       # no-op for a single replica
     self.optimizer.apply_gradients(self)
     if want_metric:
       sample = self.sample_waveform(pred)
