@@ -92,6 +92,7 @@ int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t T, int32_t
 /* ---- measurement hook (bench.py): HIP events around each residual-block forward launch on
  * the caller's stream; wn_prof_read returns the average per-launch time after a stream sync.
  * Not part of the reference surface. */
+int wn_debug_set(int key, int value);     /* tuning knobs for tools/ scripts */
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
 int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
 

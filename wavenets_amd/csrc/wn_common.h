@@ -99,3 +99,4 @@ __device__ __forceinline__ void wn_static_for(F&& f) {
   } while (0)
 
 void wn_set_error(const char* fmt, ...);
+int wn_debug_get(int key);   // tuning knobs (wn_error.cpp): 0 = layer-forward kernel variant

@@ -9,13 +9,45 @@
 //                       and every backward-data product.
 //  * wn_wgrad         : dW[k][n] = sum_t X[t - shift][k] * G[t][n]  (time is the MFMA K
 //                       dimension), split over time into partial slabs + deterministic reduce.
+#include <hip/hip_fp16.h>
+
 #include "wn_kernels.h"
 
 // ------------------------------------------------------------------------------------------
 // weight preparation
 // ------------------------------------------------------------------------------------------
+// fp16 hi/lo split image for v_mfma_f32_32x32x16_f16: per (k-step ks of 16, row tile j) two 1 KiB
+// blocks (hi then lo); lane l holds 8 halfs, element jj <-> contraction index
+// 16 ks + 8 (jj >> 2) + 4 (l >> 5) + (jj & 3)  -- the order in which a 32x32 accumulator tile's
+// registers present their rows, so that tile can feed the next MFMA unchanged.
+__device__ __forceinline__ void wn_prep16_body(const WnPrepDesc& d, const float* params, float* ws,
+                                               int64_t start, int64_t stride) {
+  const int JI = (d.I + 31) / 32;
+  const int nks = (d.KK + 15) / 16;
+  const int64_t total = (int64_t)nks * JI * 64 * 8;
+  const float* src = params + d.src_off;
+  __half* dst = reinterpret_cast<__half*>(ws + d.dst_off);
+  for (int64_t idx = start; idx < total; idx += stride) {
+    const int jj = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int64_t blk = idx >> 9;
+    const int j = blk % JI;
+    const int ks = blk / JI;
+    const int i = 32 * j + (lane & 31);
+    const int kk = 16 * ks + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
+    float v = 0.f;
+    if (i < d.I && kk < d.KK) v = d.transpose ? src[(int64_t)kk * d.ld + i] : src[(int64_t)i * d.ld + kk];
+    const __half hi = __float2half_rn(v);
+    const __half lo = __float2half_rn(v - __half2float(hi));
+    const int64_t base = (((int64_t)(ks + d.q_off) * d.JT + (j + d.j_off)) * 2) * 512 + lane * 8 + jj;
+    dst[base] = hi;
+    dst[base + 512] = lo;
+  }
+}
+
 __device__ __forceinline__ void wn_prep_body(const WnPrepDesc& d, const float* params, float* ws,
                                              int64_t start, int64_t stride) {
+  if (d.kind == 1) { wn_prep16_body(d, params, ws, start, stride); return; }
   const int JI = (d.I + 31) / 32;          // row tiles of this piece (== d.JT for whole images)
   const int nq = (d.KK + 7) / 8;
   const int64_t total = (int64_t)nq * JI * 256;

@@ -18,7 +18,7 @@ struct WnPrepDesc {
   int32_t q_off;     // first k-quad of this piece inside a larger concatenated image
   int32_t j_off;     // first row tile of this piece inside a larger stacked image
   int32_t JT;        // row tiles of the whole image
-  int32_t pad_;
+  int32_t kind;      // 0: fp32 fragment image; 1: fp16 hi/lo split image for the 32x32x16 MFMA (q_off counts k-steps of 16)
 };
 int wn_launch_prep_table(const WnPrepDesc* d_table, int n, const float* params, float* ws,
                          hipStream_t s);
@@ -105,6 +105,10 @@ struct WnLayerFwdArgs {
   int32_t B, T, R, D, KS, dilation, residual;
 };
 int wn_layer_fwd_supported(int R, int D, int KS);
+// fp16 hi/lo split (3-product) variant with LDS-resident weights; frag_d / frag_r are kind-1 images
+int wn_layer_fwd_f16_supported(int R, int D, int KS);
+int wn_launch_layer_fwd_f16(const WnLayerFwdArgs& a, hipStream_t s);
+size_t wn_frag16_floats(int I, int KK);
 int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise / loss / sampling

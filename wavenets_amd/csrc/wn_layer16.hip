@@ -1,0 +1,261 @@
+// Fused WaveNet residual block forward, split-precision MFMA variant (gfx950).
+// Reference: WaveNetLayer.call, src/layers.py:178-224 (depth-1 dilated stack).
+//
+// Same chain and register orientation as wn_layer.hip (time on lanes; accumulator tiles feed the
+// next contraction unchanged), but every fp32 product a*b is evaluated as
+//     a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,   a = a_hi + a_lo  (fp16 hi / lo, fp32 accumulate)
+// on v_mfma_f32_32x32x16_f16: 3 MFMAs of 16 k each instead of 8 fp32 MFMAs of 2 k -> 5.3x fewer
+// matrix-pipe cycles at |error| <= ~6e-7 on O(1) results (tools/f16_split_probe.hip; the MFMA
+// keeps fp16 subnormals, so the lo parts never flush).  That moves the block from the fp32-MFMA
+// bound to the HBM bound the roofline contract asks for, so the rest of the kernel is built as a
+// streaming kernel:
+//   * persistent workgroups (8 waves, one per CU), weight images (hi|lo) resident in LDS
+//   * every output tile (x_out, z, tanh, sigmoid) is transposed through a wave-private LDS
+//     stage and leaves as full 256-byte row segments (1 KiB per wave store instruction)
+//   * no barrier inside the tile loop: waves only share the read-only weights.
+#include <hip/hip_fp16.h>
+
+#include "wn_kernels.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 wn_mfma16(h8 a, h8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// split 8 fp32 values (two float4 quads) into fp16 hi / lo fragments
+__device__ __forceinline__ void wn_split8(const f32x4& q0, const f32x4& q1, h8& hi, h8& lo) {
+  const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)v[e];
+    hi[e] = h;
+    lo[e] = (_Float16)(v[e] - (float)h);
+  }
+}
+
+template <int R32, int D32, int KS>
+struct WnL16 {
+  static constexpr int R = 32 * R32, D = 32 * D32, JU = 2 * D32;
+  static constexpr int KS1 = KS * R / 16;        // k-steps of the dilated conv
+  static constexpr int KS2 = D / 16;             // k-steps of the 1x1 conv
+  static constexpr int WD_BYTES = KS1 * JU * 2048;
+  static constexpr int WR_BYTES = KS2 * R32 * 2048;
+  static constexpr int CMAX = (R > D ? R : D);
+  static constexpr int PITCH = CMAX + 4;         // floats; +4 keeps b128 accesses conflict-free
+  static constexpr int STAGE_BYTES = 32 * PITCH * 4;
+  static constexpr int WAVES = 8;
+  static constexpr int LDS_BYTES = WD_BYTES + WR_BYTES + WAVES * STAGE_BYTES;
+};
+
+// tile (32 rows x C floats) held as D-layout registers -> LDS stage -> coalesced rows in HBM
+template <int C32, int PITCH>
+__device__ __forceinline__ void wn_store_tile(const f32x16 (&v)[C32], float* stage, float* dst, int64_t ld,
+                                              int rows_valid, int lane) {
+  const int tl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < C32; ++j)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 o;
+      o.x = v[j][4 * rq + 0]; o.y = v[j][4 * rq + 1]; o.z = v[j][4 * rq + 2]; o.w = v[j][4 * rq + 3];
+      *reinterpret_cast<f32x4*>(stage + tl * PITCH + 32 * j + 8 * rq + 4 * h) = o;
+    }
+  // LDS instructions of one wave execute in order, so the reads below see every lane's writes;
+  // the asm statements only stop the compiler from moving LDS accesses across the two phases
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  constexpr int LPR = C32 * 8;                 // lanes (16-byte pieces) per row
+  constexpr int RPI = 64 / LPR;                // rows per store instruction
+#pragma unroll
+  for (int i = 0; i < 32 / RPI; ++i) {
+    const int row = i * RPI + lane / LPR;
+    const int col = (lane % LPR) * 4;
+    const f32x4 o = *reinterpret_cast<const f32x4*>(stage + row * PITCH + col);
+    if (row < rows_valid) *reinterpret_cast<f32x4*>(dst + (int64_t)row * ld + col) = o;
+  }
+  asm volatile("" ::: "memory");
+}
+
+template <int R32, int D32, int KS>
+__global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs a) {
+  using G = WnL16<R32, D32, KS>;
+  constexpr int R = G::R, D = G::D, JU = G::JU, KS1 = G::KS1, KS2 = G::KS2, PITCH = G::PITCH;
+  constexpr int QR = R / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tl = lane & 31, h = lane >> 5;
+
+  // ---- weights: global (fp16 hi|lo images) -> LDS, once per workgroup ----
+  {
+    const f32x4* gd = reinterpret_cast<const f32x4*>(a.frag_d);
+    const f32x4* gr = reinterpret_cast<const f32x4*>(a.frag_r);
+    f32x4* sd = reinterpret_cast<f32x4*>(smem);
+    f32x4* sr = reinterpret_cast<f32x4*>(smem + G::WD_BYTES);
+    for (int i = tid; i < G::WD_BYTES / 16; i += 512) sd[i] = gd[i];
+    for (int i = tid; i < G::WR_BYTES / 16; i += 512) sr[i] = gr[i];
+  }
+  __syncthreads();
+  const h8* wd = reinterpret_cast<const h8*>(smem) + lane;                 // block b -> wd[b * 64]
+  const h8* wr = reinterpret_cast<const h8*>(smem + G::WD_BYTES) + lane;
+  float* stage = reinterpret_cast<float*>(smem + G::WD_BYTES + G::WR_BYTES + wave * G::STAGE_BYTES);
+
+  const int tiles_per_b = (a.T + 31) >> 5;
+  const int64_t ntiles = (int64_t)a.B * tiles_per_b;
+  for (int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * G::WAVES) {
+    const int b = (int)(tile / tiles_per_b);
+    const int t0 = (int)(tile % tiles_per_b) * 32;
+    const int t = t0 + tl;
+    const bool tin = t < a.T;
+    const int rows_valid = min(32, a.T - t0);
+    const int64_t row0 = (int64_t)b * a.T + t0;
+
+    // ---- activation loads of all taps, issued up front (unconditional, clamped row) ----
+    f32x4 xq[KS][QR];
+    bool xvalid[KS];
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap) {
+      const int ts = t - (KS - 1 - tap) * a.dilation;
+      xvalid[tap] = tin && ts >= 0;
+      const float* xrow = a.x + ((int64_t)b * a.T + (xvalid[tap] ? ts : 0)) * R + 4 * h;
+#pragma unroll
+      for (int q = 0; q < QR; ++q) xq[tap][q] = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
+    }
+    // ---- accumulators start at the bias (+ per-utterance conditioning bias) ----
+    f32x16 u[JU];
+#pragma unroll
+    for (int j = 0; j < JU; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias_d + 32 * j + 8 * rq + 4 * h);
+        u[j][4 * rq + 0] = bv.x; u[j][4 * rq + 1] = bv.y; u[j][4 * rq + 2] = bv.z; u[j][4 * rq + 3] = bv.w;
+      }
+    if (a.cb) {   // wave-uniform
+      const float* cbp = a.cb + (int64_t)b * 2 * D + 4 * h;
+#pragma unroll
+      for (int j = 0; j < JU; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(cbp + 32 * j + 8 * rq);
+          u[j][4 * rq + 0] += cv.x; u[j][4 * rq + 1] += cv.y; u[j][4 * rq + 2] += cv.z; u[j][4 * rq + 3] += cv.w;
+        }
+    }
+
+    // ---- dilated causal conv: KS1 k-steps of 16, 3 MFMAs per (k-step, tile) ----
+    wn_static_for<KS1>([&](auto sc) {
+      constexpr int ks = decltype(sc)::value;
+      constexpr int tap = ks / (R / 16), kk = ks % (R / 16);
+      f32x4 q0 = xq[tap][2 * kk], q1 = xq[tap][2 * kk + 1];
+      if (!xvalid[tap]) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+      h8 bh, bl;
+      wn_split8(q0, q1, bh, bl);
+#pragma unroll
+      for (int j = 0; j < JU; ++j) {
+        const h8 ah = wd[((ks * JU + j) * 2 + 0) * 64];
+        const h8 al = wd[((ks * JU + j) * 2 + 1) * 64];
+        u[j] = wn_mfma16(al, bh, u[j]);
+        u[j] = wn_mfma16(ah, bl, u[j]);
+        u[j] = wn_mfma16(ah, bh, u[j]);
+      }
+    });
+
+    // ---- gate; a / g tiles reuse the accumulator registers ----
+    //      u[j] (filter) -> z, u[j + D32] (gate) -> sigmoid; tanh kept in a separate tile set only
+    //      while it is being written out
+    if (a.ag_out) {
+      f32x16 av[D32];
+#pragma unroll
+      for (int j = 0; j < D32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          av[j][r] = wn_tanh_fast(u[j][r]);
+          u[j + D32][r] = wn_sigmoid_fast(u[j + D32][r]);
+          u[j][r] = av[j][r] * u[j + D32][r];
+        }
+      if (rows_valid > 0) {
+        wn_store_tile<D32, PITCH>(av, stage, a.ag_out + row0 * 2 * D, 2 * D, rows_valid, lane);
+        f32x16 gv[D32];
+#pragma unroll
+        for (int j = 0; j < D32; ++j) gv[j] = u[j + D32];
+        wn_store_tile<D32, PITCH>(gv, stage, a.ag_out + row0 * 2 * D + D, 2 * D, rows_valid, lane);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < D32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[j][r] = wn_tanh_fast(u[j][r]) * wn_sigmoid_fast(u[j + D32][r]);
+    }
+    if (a.z_out && rows_valid > 0) {
+      f32x16 zv[D32];
+#pragma unroll
+      for (int j = 0; j < D32; ++j) zv[j] = u[j];
+      wn_store_tile<D32, PITCH>(zv, stage, a.z_out + row0 * a.ldz, a.ldz, rows_valid, lane);
+    }
+
+    // ---- 1x1 residual conv: B operand = z tiles as they stand (rows 8s..8s+7 of a tile = k-step) ----
+    f32x16 o[R32];
+#pragma unroll
+    for (int j = 0; j < R32; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias_r + 32 * j + 8 * rq + 4 * h);
+        o[j][4 * rq + 0] = bv.x; o[j][4 * rq + 1] = bv.y; o[j][4 * rq + 2] = bv.z; o[j][4 * rq + 3] = bv.w;
+      }
+    wn_static_for<KS2>([&](auto sc) {
+      constexpr int ks = decltype(sc)::value;
+      constexpr int jz = ks / 2, r0 = 8 * (ks % 2);
+      f32x4 q0, q1;
+      q0.x = u[jz][r0 + 0]; q0.y = u[jz][r0 + 1]; q0.z = u[jz][r0 + 2]; q0.w = u[jz][r0 + 3];
+      q1.x = u[jz][r0 + 4]; q1.y = u[jz][r0 + 5]; q1.z = u[jz][r0 + 6]; q1.w = u[jz][r0 + 7];
+      h8 bh, bl;
+      wn_split8(q0, q1, bh, bl);
+#pragma unroll
+      for (int j = 0; j < R32; ++j) {
+        const h8 ah = wr[((ks * R32 + j) * 2 + 0) * 64];
+        const h8 al = wr[((ks * R32 + j) * 2 + 1) * 64];
+        o[j] = wn_mfma16(al, bh, o[j]);
+        o[j] = wn_mfma16(ah, bl, o[j]);
+        o[j] = wn_mfma16(ah, bh, o[j]);
+      }
+    });
+
+    if (rows_valid > 0) {
+      if (a.o_out) wn_store_tile<R32, PITCH>(o, stage, a.o_out + row0 * R, R, rows_valid, lane);
+      if (a.residual) {
+#pragma unroll
+        for (int j = 0; j < R32; ++j)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            f32x4 xr;
+            if (a.res) xr = tin ? *reinterpret_cast<const f32x4*>(a.res + (row0 + tl) * R + 32 * j + 8 * rq + 4 * h)
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+            else xr = xq[KS - 1][j * 4 + rq];
+            o[j][4 * rq + 0] += xr.x; o[j][4 * rq + 1] += xr.y; o[j][4 * rq + 2] += xr.z; o[j][4 * rq + 3] += xr.w;
+          }
+      }
+      wn_store_tile<R32, PITCH>(o, stage, a.x_out + row0 * R, R, rows_valid, lane);
+    }
+  }
+}
+
+size_t wn_frag16_floats(int I, int KK) { return (size_t)((KK + 15) / 16) * ((I + 31) / 32) * 512; }
+
+int wn_layer_fwd_f16_supported(int R, int D, int KS) {
+  if (R == 32 && D == 32) return KS == 2 || KS == 3;
+  if (R == 64 && D == 64) return KS == 2;    // LDS: 64 KiB W_d + 16 KiB W_r + 68 KiB stages
+  return 0;
+}
+
+int wn_launch_layer_fwd_f16(const WnLayerFwdArgs& a, hipStream_t s) {
+  const int64_t tiles = (int64_t)a.B * ((a.T + 31) / 32);
+  if (tiles <= 0) return WN_OK;
+  int64_t gx = (tiles + 7) / 8;
+  if (gx > 256) gx = 256;                    // one persistent workgroup per CU
+  if (a.R == 32 && a.KS == 2) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<1, 1, 2>), dim3((unsigned)gx), dim3(512), 0, s, a);
+  else if (a.R == 32 && a.KS == 3) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<1, 1, 3>), dim3((unsigned)gx), dim3(512), 0, s, a);
+  else if (a.R == 64 && a.KS == 2) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<2, 2, 2>), dim3((unsigned)gx), dim3(512), 0, s, a);
+  else { wn_set_error("layer_fwd_f16: unsupported shape R=%d D=%d KS=%d", a.R, a.D, a.KS); return WN_E_UNSUPPORTED; }
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

@@ -37,6 +37,7 @@ struct ConvInfo {
   int64_t fragF = -1;   // taps images of A[cout][cin]  (forward:  A[n][k] = W[tap][k][n])
   int64_t fragB = -1;   // taps images of A[cin][cout]  (backward: A[k][n] = W[tap][k][n])
   int64_t fragF_stride = 0, fragB_stride = 0;
+  int64_t frag16 = -1;  // fp16 hi/lo split forward image (all taps concatenated along k), or -1
 };
 
 struct BlockInfo {
@@ -64,7 +65,7 @@ struct wn_plan {
   WnPrepDesc* d_prep = nullptr;
   WnTensorDesc* d_tdesc = nullptr;
   WnTensorDesc* d_kdesc = nullptr;
-  bool fused_ok = false;
+  bool fused_ok = false, fused16_ok = false;
   // batched weight-gradient job table (device), valid for one (B, T) workspace layout
   WnWgJob* d_jobs = nullptr;
   WnTensorDesc* d_cov = nullptr;
@@ -135,6 +136,22 @@ void add_images(wn_plan* p, ConvInfo& c, bool fwd, bool bwd) {
     }
     p->frag_floats += c.taps * c.fragB_stride;
   }
+}
+
+// forward fp16 hi/lo split image A[cout][taps*cin] for the split-precision block kernel
+void add_image16(wn_plan* p, ConvInfo& c) {
+  const TensorInfo& k = p->tensors[c.kernel_t];
+  c.frag16 = p->frag_floats;
+  for (int t = 0; t < c.taps; ++t) {
+    WnPrepDesc d;
+    memset(&d, 0, sizeof(d));
+    d.src_off = k.off + (int64_t)t * c.cin * c.cout;
+    d.dst_off = c.frag16;
+    d.I = c.cout; d.KK = c.cin; d.ld = c.cout; d.transpose = 1;
+    d.q_off = t * (c.cin / 16); d.j_off = 0; d.JT = ceil32(c.cout); d.kind = 1;
+    p->prep.push_back(d);
+  }
+  p->frag_floats += (int64_t)wn_frag16_floats(c.cout, c.taps * c.cin);
 }
 
 int ensure_device_tables(wn_plan* p) {
@@ -385,6 +402,7 @@ struct BlockPtrs {
   const float* cond;        // [rows][Cc]
   const float* cb;          // [B][2D] per-utterance conditioning bias (model) or null
   bool fused;
+  const float* F16d; const float* F16r;   // fp16 split images of the gated conv / conv1, or null
 };
 
 struct BlockBufs {
@@ -413,11 +431,14 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
   if (k.fused && k.Cc == 0 && hc == k.R) {
     WnLayerFwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = h; a.frag_d = k.Fd[li]; a.frag_r = k.Fr; a.bias_d = k.bd[li]; a.bias_r = k.br; a.cb = k.cb;
+    // knob 1 = 1 forces the exact-fp32 MFMA kernel
+    const bool use16 = k.F16d && k.F16r && wn_debug_get(1) != 1;
+    a.x = h; a.frag_d = use16 ? k.F16d : k.Fd[li]; a.frag_r = use16 ? k.F16r : k.Fr;
+    a.bias_d = k.bd[li]; a.bias_r = k.br; a.cb = k.cb;
     a.x_out = f.x_out; a.o_out = f.O; a.z_out = f.Z; a.ldz = f.ldz; a.ag_out = f.AG;
     a.res = (k.depth > 1) ? f.x : nullptr;
     a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
-    return wn_launch_layer_fwd(a, s);
+    return use16 ? wn_launch_layer_fwd_f16(a, s) : wn_launch_layer_fwd(a, s);
   }
   // composed path: u -> gate -> 1x1
   {
@@ -659,6 +680,12 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
   }
   p->frag_floats += (int64_t)wn_frag_floats(p->Sh, p->N * p->Dp);
   p->fused_ok = wn_layer_fwd_supported(p->R, p->D, p->KS) != 0;
+  p->fused16_ok = p->fused_ok && wn_layer_fwd_f16_supported(p->R, p->D, p->KS) != 0;
+  if (p->fused16_ok)
+    for (BlockInfo& bi : p->blocks) {
+      add_image16(p, bi.dil.back());
+      add_image16(p, bi.conv1);
+    }
   return p;
 }
 
@@ -754,6 +781,7 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   if (bi.has_skip) { k.bs = params + p->tensors[bi.conv_skip.bias_t].off; k.Bs = fragbase + bi.conv_skip.fragB; }
   k.Cc = 0; k.cond = nullptr; k.cb = nullptr;
   k.fused = p->fused_ok;
+  if (p->fused16_ok && p->LPB == 1) { k.F16d = fragbase + bi.dil.back().frag16; k.F16r = fragbase + bi.conv1.frag16; }
   return k;
 }
 
@@ -1294,6 +1322,7 @@ struct LayerLayout {
   // workspace
   int64_t Fd[16], Bd[16], Fd_stride[16], Bd_stride[16], Fr, Br, Bs, Fs, Fc, Bc;
   int64_t bias_u, U, O, g_u, g_o, g_p, slab, ws_total;
+  int64_t F16d, F16r;   // fp16 split images (or -1)
   // saved
   int64_t sP[16], sAG, sZ, saved_total;
 };
@@ -1332,6 +1361,12 @@ int layer_layout(const wn_layer_desc* d, int B, int T, LayerLayout& L) {
   L.Bs = cv.take(S > 0 ? (int64_t)wn_frag_floats(D, S) : 0);
   L.Fc = cv.take(Cc > 0 ? (int64_t)wn_frag_floats(2 * D, Cc) : 0);
   L.Bc = cv.take(Cc > 0 ? (int64_t)wn_frag_floats(Cc, 2 * D) : 0);
+  L.F16d = L.F16r = -1;
+  if (d->depth == 1 && Cc == 0 && cin == 2 * D && (d->in_channels > 0 ? d->in_channels : R) == R &&
+      wn_layer_fwd_supported(R, D, KS) && wn_layer_fwd_f16_supported(R, D, KS)) {
+    L.F16d = cv.take((int64_t)wn_frag16_floats(2 * D, KS * R));
+    L.F16r = cv.take((int64_t)wn_frag16_floats(R, D));
+  }
   L.bias_u = cv.take(2 * D);
   L.U = cv.take(rows * 2 * D);
   L.O = cv.take(rows * R);
@@ -1374,6 +1409,19 @@ int layer_prep(const wn_layer_desc* d, const LayerLayout& L, const float* params
     }
   if ((rc = one(L.Wr, L.Fr, R, D, R, 1))) return rc;
   if ((rc = one(L.Wr, L.Br, D, R, R, 0))) return rc;
+  if (L.F16d >= 0) {
+    for (int t = 0; t < KS; ++t) {
+      WnPrepDesc pd;
+      memset(&pd, 0, sizeof(pd));
+      pd.src_off = L.Wd[0] + (int64_t)t * R * 2 * D; pd.dst_off = L.F16d; pd.I = 2 * D; pd.KK = R; pd.ld = 2 * D;
+      pd.transpose = 1; pd.q_off = t * (R / 16); pd.JT = (2 * D + 31) / 32; pd.kind = 1;
+      if ((rc = wn_launch_prep_one(pd, params, ws, s))) return rc;
+    }
+    WnPrepDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.src_off = L.Wr; pd.dst_off = L.F16r; pd.I = R; pd.KK = D; pd.ld = R; pd.transpose = 1; pd.JT = (R + 31) / 32; pd.kind = 1;
+    if ((rc = wn_launch_prep_one(pd, params, ws, s))) return rc;
+  }
   if (S > 0) {
     if ((rc = one(L.Ws, L.Fs, S, D, S, 1))) return rc;
     if ((rc = one(L.Ws, L.Bs, D, S, S, 0))) return rc;
@@ -1406,6 +1454,7 @@ void layer_ptrs(const wn_layer_desc* d, const LayerLayout& L, const float* param
   k.Cc = d->cond_channels; k.cond = cond; k.cb = nullptr;
   if (k.Cc > 0) { k.Fc = ws + L.Fc; k.Bc = ws + L.Bc; k.bc = params + L.bc; k.bd[d->depth - 1] = ws + L.bias_u; }
   k.fused = wn_layer_fwd_supported(R, D, d->kernel_size) != 0;
+  if (L.F16d >= 0) { k.F16d = ws + L.F16d; k.F16r = ws + L.F16r; }
 }
 
 }  // namespace
