@@ -98,5 +98,12 @@ __device__ __forceinline__ void wn_static_for(F&& f) {
     }                                                        \
   } while (0)
 
+// running max-abs of a tensor (non-negative floats order like their bit patterns); the plain read
+// first keeps almost every wave off the atomic (one address: contention would serialise them)
+__device__ __forceinline__ void wn_absmax_publish(float* slot, float v) {
+  if (v > 0.f && v < 3.0e38f && v > *reinterpret_cast<volatile float*>(slot))
+    atomicMax(reinterpret_cast<int*>(slot), __float_as_int(v));
+}
+
 void wn_set_error(const char* fmt, ...);
 int wn_debug_get(int key);   // tuning knobs (wn_error.cpp): 0 = layer-forward kernel variant

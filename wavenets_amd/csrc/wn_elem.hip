@@ -169,7 +169,7 @@ int wn_launch_softmax(const float* logits, float* probs, int64_t rows, int C, hi
 // and its gradient w.r.t. the logits (clip passes gradient where eps <= q <= 1-eps).
 __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, const int32_t* target,
                                                           int64_t rows, int C, float gscale,
-                                                          float* loss_rows, float* g_logits) {
+                                                          float* loss_rows, float* g_logits, float* absmax_out) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, c
   const float ct = (qt >= WN_KERAS_EPS && qt <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
   if (lane == 0) loss_rows[row] = -(logf(pt) - logf(S));
   if (g_logits) {
+    float gmax = 0.f;
     const float invS = 1.0f / S;
     const float dot = A * invS - ct * qt / pt;     // sum_j g_j q_j
     for (int j = lane; j < C; j += 64) {
@@ -204,15 +205,21 @@ __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, c
       const float c = (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
       float g = c * invS;
       if (j == tgt) g -= ct / pt;
-      g_logits[row * C + j] = gscale * q * (g - dot);
+      const float gl = gscale * q * (g - dot);
+      g_logits[row * C + j] = gl;
+      gmax = fmaxf(gmax, fabsf(gl));
+    }
+    if (absmax_out) {
+      gmax = wn_wave_max(gmax);
+      if (lane == 0) wn_absmax_publish(absmax_out, gmax);
     }
   }
 }
 int wn_launch_cat_loss(const float* logits, const int32_t* target, int64_t rows, int C,
-                       float gscale, float* loss_rows, float* g_logits, hipStream_t s) {
+                       float gscale, float* loss_rows, float* g_logits, float* absmax_out, hipStream_t s) {
   if (rows <= 0) return WN_OK;
   hipLaunchKernelGGL(wn_cat_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
-                     target, rows, C, gscale, loss_rows, g_logits);
+                     target, rows, C, gscale, loss_rows, g_logits, absmax_out);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
@@ -247,7 +254,7 @@ int wn_launch_cat_loss_probs(const float* probs, const int32_t* target, int64_t 
 #define WN_MAXMIX 32
 __device__ __forceinline__ double wn_sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 __global__ void wn_mix_loss_kernel(const float* pred, const float* y, int64_t rows, int M, int bits,
-                                   int kind, float gscale, float* loss_rows, float* g_pred) {
+                                   int kind, float gscale, float* loss_rows, float* g_pred, float* absmax_out) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   const float* p = pred + row * 3 * M;
@@ -303,13 +310,18 @@ __global__ void wn_mix_loss_kernel(const float* pred, const float* y, int64_t ro
       g[2 * M + k] = (float)(dl * lsmask * w[k] * pdf * (xx * xx * xmask - 1.0));
     }
   }
+  if (absmax_out) {
+    float gmax = 0.f;
+    for (int k = 0; k < 3 * M; ++k) gmax = fmaxf(gmax, fabsf(g[k]));
+    wn_absmax_publish(absmax_out, gmax);
+  }
 }
 int wn_launch_mix_loss(const float* pred, const float* y, int64_t rows, int M, int bits, int kind,
-                       float gscale, float* loss_rows, float* g_pred, hipStream_t s) {
+                       float gscale, float* loss_rows, float* g_pred, float* absmax_out, hipStream_t s) {
   if (rows <= 0) return WN_OK;
   if (M < 1 || M > WN_MAXMIX) { wn_set_error("mix_loss: num_mixtures %d unsupported (max %d)", M, WN_MAXMIX); return WN_E_UNSUPPORTED; }
   hipLaunchKernelGGL(wn_mix_loss_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, pred,
-                     y, rows, M, bits, kind, gscale, loss_rows, g_pred);
+                     y, rows, M, bits, kind, gscale, loss_rows, g_pred, absmax_out);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

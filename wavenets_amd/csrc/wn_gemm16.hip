@@ -1,0 +1,319 @@
+// Rows GEMM, split-precision MFMA variant (gfx950):
+//   Y[t][n] = epi( sum_seg sum_k X_seg[t - shift_seg][k] * W[k_seg + k][n] )
+// Same contract as wn_gemm_rows_kernel (wn_gemm.hip) but each fp32 product is evaluated as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 (see wn_layer16.hip), and the kernel
+// is organised as a streaming GEMM:
+//   * persistent workgroups of 8 waves (256 rows per pass); the fp16 hi|lo weight image of ALL
+//     segments is one concatenated sequence of 2 KiB (k-step, row-tile) blocks that the
+//     workgroup streams through a double-buffered LDS ring in chunks (one barrier per chunk),
+//     so L2 weight traffic drops 8x versus one weight pass per wave
+//   * output tiles leave through a wave-private LDS stage as full row segments
+//   * gradient operands are pre-scaled by an exact power of two taken from a device-side
+//     running max-abs of the tensor (written by the producing kernel), so that their fp16 lo
+//     parts do not sink into the fp16 subnormal range; the accumulators are scaled back exactly.
+#include <hip/hip_fp16.h>
+
+#include "wn_kernels.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 wn_mfma16g(h8 a, h8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wn_split8g(const f32x4& q0, const f32x4& q1, float s, h8& hi, h8& lo) {
+  const float v[8] = {q0.x * s, q0.y * s, q0.z * s, q0.w * s, q1.x * s, q1.y * s, q1.z * s, q1.w * s};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)v[e];
+    hi[e] = h;
+    lo[e] = (_Float16)(v[e] - (float)h);
+  }
+}
+
+// chunk = CH (k-step, row-tile) blocks of 2 KiB  ->  KSC = CH / JT k-steps per chunk
+template <int JT>
+struct WnG16 {
+  static constexpr int CH = 8;                        // blocks per chunk
+  static constexpr int KSC = CH / JT;                 // k-steps per chunk: 4, 2 for JT = 2, 4
+  static constexpr int CHUNK_BYTES = CH * 2048;       // 16 KiB
+  static constexpr int SC = 64;                       // stage width in channels
+  static constexpr int PITCH = SC + 4;
+  static constexpr int STAGE_BYTES = 32 * PITCH * 4;  // 8704
+  static constexpr int WAVES = 8;
+  static constexpr int LDS_BYTES = 2 * CHUNK_BYTES + WAVES * STAGE_BYTES;   // 135168
+};
+
+template <int JT>
+__global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, const float* w16, int nks_total,
+                                                                const float* absmax_in0, const float* absmax_in1,
+                                                                float* absmax_out) {
+  using G = WnG16<JT>;
+  constexpr int KSC = G::KSC, PITCH = G::PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tl = lane & 31, h = lane >> 5;
+  float* stage = reinterpret_cast<float*>(smem + 2 * G::CHUNK_BYTES + wave * G::STAGE_BYTES);
+
+  // exact power-of-two operand scale from the producers' running max-abs
+  float sc = 1.0f, inv_sc = 1.0f;
+  if (absmax_in0) {
+    float m = *absmax_in0;
+    if (absmax_in1) m = fmaxf(m, *absmax_in1);
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);               // m = f * 2^e, f in [0.5, 1)
+      e = max(-100, min(100, e));
+      sc = ldexpf(1.0f, -e);             // scaled values lie in [-1, 1)
+      inv_sc = ldexpf(1.0f, e);
+    }
+  }
+
+  const int tiles_per_b = (a.T + 31) >> 5;
+  const int64_t ntiles = (int64_t)a.B * tiles_per_b;
+  const int nchunks = (nks_total + KSC - 1) / KSC;
+  const int64_t passes = (ntiles + (int64_t)gridDim.x * G::WAVES - 1) / ((int64_t)gridDim.x * G::WAVES);
+  const int jb = blockIdx.y * JT;                      // first row tile of this block (N > 32*JT)
+
+  // k-step boundaries of the segments (static indices: no private-memory copy of the args)
+  int ks_end[WN_MAXSEG];
+  {
+    int acc = 0;
+#pragma unroll
+    for (int s = 0; s < WN_MAXSEG; ++s) {
+      if (s < a.nseg) acc += (a.seg[s].K + 15) >> 4;
+      ks_end[s] = acc;
+    }
+  }
+  float wmax = 0.f;
+
+  for (int64_t pass = 0; pass < passes; ++pass) {
+    const int64_t tile = (pass * gridDim.x + blockIdx.x) * G::WAVES + wave;
+    const bool live = tile < ntiles;                   // dead waves still take part in the barriers
+    const int b = live ? (int)(tile / tiles_per_b) : 0;
+    const int t0 = live ? (int)(tile % tiles_per_b) * 32 : 0;
+    const int t = t0 + tl;
+    const int rows_valid = live ? min(32, a.T - t0) : 0;
+    const int64_t row0 = (int64_t)b * a.T + t0;
+
+    // per-segment row pointer of this lane (hoisted: the chunk loop then needs no segment fields)
+    const float* xrow_s[WN_MAXSEG];
+    bool xok_s[WN_MAXSEG];
+#pragma unroll
+    for (int s = 0; s < WN_MAXSEG; ++s) {
+      xrow_s[s] = nullptr;
+      xok_s[s] = false;
+      if (s < a.nseg) {
+        const int ts = t - a.seg[s].shift;
+        xok_s[s] = live && t < a.T && ts >= 0 && ts < a.T;
+        xrow_s[s] = a.seg[s].x + ((int64_t)b * a.T + (xok_s[s] ? ts : 0)) * a.seg[s].ldx + 4 * h;
+      }
+    }
+    // activations of global k-step ks for this lane: two float4 quads (channels 16kk+4h.., 16kk+8+4h..)
+    auto load_x = [&](int ks, f32x4& q0, f32x4& q1) {
+      q0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      q1 = q0;
+      if (ks >= nks_total) return;
+      const float* xr = xrow_s[0];
+      bool ok = xok_s[0];
+      int kk = ks;
+#pragma unroll
+      for (int s = 1; s < WN_MAXSEG; ++s)
+        if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }   // wave-uniform
+      if (ok) {
+        q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
+        q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
+      }
+    };
+    // weight chunk c: global -> LDS buffer (c & 1) by LDS-DMA (no registers): every wave instruction
+    // moves one contiguous KiB (wave-uniform LDS base + lane * 16).  Blocks past the end of the image
+    // are clamped to a valid block: their activations are zero, so they only need to be finite.
+    auto wdma = [&](int c) {
+      constexpr int PER_THREAD = G::CHUNK_BYTES / 16 / 512;      // 2 or 4
+#pragma unroll
+      for (int i = 0; i < PER_THREAD; ++i) {
+        const int f = tid + 512 * i;                   // 16-byte piece inside the chunk
+        const int blk = f >> 7, within = f & 127;
+        int ks = c * KSC + blk / JT, j = jb + blk % JT;
+        ks = min(ks, nks_total - 1);
+        j = min(j, a.JTtot - 1);
+        const f32x4* src = reinterpret_cast<const f32x4*>(w16) + ((int64_t)ks * a.JTtot + j) * 128 + within;
+        unsigned char* dst = smem + (c & 1) * G::CHUNK_BYTES + (512 * i + wave * 64) * 16;   // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+
+    f32x16 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    f32x4 xa[KSC][2], xb[KSC][2];
+    __syncthreads();                                   // previous pass finished with both buffers
+    wdma(0);
+#pragma unroll
+    for (int k = 0; k < KSC; ++k) load_x(k, xa[k][0], xa[k][1]);
+    __syncthreads();                                   // (the barrier's fence drains the DMA: vmcnt(0))
+
+    auto compute = [&](int c, const f32x4 (&xv)[KSC][2]) {
+      const h8* wl = reinterpret_cast<const h8*>(smem + (c & 1) * G::CHUNK_BYTES) + lane;
+      // (k-step, tile) blocks in order; the next block's hi|lo fragments are read one block ahead and
+      // the schedule is pinned per block so that the compiler does not hoist a whole chunk of LDS reads
+      h8 fr[2][2];
+      fr[0][0] = wl[0];
+      fr[0][1] = wl[64];
+      wn_static_for<KSC * JT>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value;
+        constexpr int k = blk / JT, j = blk % JT;
+        if constexpr (blk + 1 < KSC * JT) {
+          fr[(blk + 1) & 1][0] = wl[((blk + 1) * 2 + 0) * 64];
+          fr[(blk + 1) & 1][1] = wl[((blk + 1) * 2 + 1) * 64];
+        }
+        h8 bh, bl;
+        wn_split8g(xv[k][0], xv[k][1], sc, bh, bl);
+        acc[j] = wn_mfma16g(fr[blk & 1][1], bh, acc[j]);
+        acc[j] = wn_mfma16g(fr[blk & 1][0], bl, acc[j]);
+        acc[j] = wn_mfma16g(fr[blk & 1][0], bh, acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+      // ---- even chunk: operands xa, prefetch into xb ----
+      if (c + 1 < nchunks) {
+        wdma(c + 1);
+#pragma unroll
+        for (int k = 0; k < KSC; ++k) load_x((c + 1) * KSC + k, xb[k][0], xb[k][1]);
+      }
+      compute(c, xa);
+      __syncthreads();
+      if (c + 1 >= nchunks) break;
+      // ---- odd chunk: operands xb, prefetch into xa ----
+      if (c + 2 < nchunks) {
+        wdma(c + 2);
+#pragma unroll
+        for (int k = 0; k < KSC; ++k) load_x((c + 2) * KSC + k, xa[k][0], xa[k][1]);
+      }
+      compute(c + 1, xb);
+      __syncthreads();
+    }
+
+    // ---- epilogue in registers (D layout), then staged row stores, 64 channels at a time ----
+    if (!live) continue;
+    const int64_t row = row0 + tl;
+    const bool tin = t < a.T;
+    // GATE_BWD produces two outputs per accumulator; they are staged one after the other
+    const int nout = (a.epi == WN_EPI_GATE_BWD) ? 2 : 1;
+    wn_static_for<(JT + 1) / 2>([&](auto gc) {
+      constexpr int g2 = decltype(gc)::value;          // pair of row tiles -> 64 channels
+      for (int part = 0; part < nout; ++part) {
+        f32x16 outv[2];
+        wn_static_for<2>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          constexpr int j = 2 * g2 + jj;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int n0 = 32 * (jb + j) + 8 * rq + 4 * h;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (j < JT && n0 < a.N && tin) {
+              v[0] = acc[j < JT ? j : 0][4 * rq + 0] * inv_sc; v[1] = acc[j < JT ? j : 0][4 * rq + 1] * inv_sc;
+              v[2] = acc[j < JT ? j : 0][4 * rq + 2] * inv_sc; v[3] = acc[j < JT ? j : 0][4 * rq + 3] * inv_sc;
+              if (a.bias) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n0);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+              }
+              if (a.rowbias) {
+                const f32x4 rb = *reinterpret_cast<const f32x4*>(a.rowbias + (int64_t)b * a.ld_rowbias + n0);
+                v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
+              }
+              if (a.addc) {
+                const f32x4 cv = *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0);
+                v[0] += cv.x; v[1] += cv.y; v[2] += cv.z; v[3] += cv.w;
+              }
+              if (a.epi == WN_EPI_PLAIN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], a.act);
+              } else if (a.epi == WN_EPI_DACT) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                v[0] *= wn_dact_from_y(yv.x, a.act); v[1] *= wn_dact_from_y(yv.y, a.act);
+                v[2] *= wn_dact_from_y(yv.z, a.act); v[3] *= wn_dact_from_y(yv.w, a.act);
+              } else {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0);
+                if (part == 0) {
+                  v[0] *= gv.x * (1.f - av.x * av.x); v[1] *= gv.y * (1.f - av.y * av.y);
+                  v[2] *= gv.z * (1.f - av.z * av.z); v[3] *= gv.w * (1.f - av.w * av.w);
+                } else {
+                  v[0] *= av.x * gv.x * (1.f - gv.x); v[1] *= av.y * gv.y * (1.f - gv.y);
+                  v[2] *= av.z * gv.z * (1.f - gv.z); v[3] *= av.w * gv.w * (1.f - gv.w);
+                }
+              }
+              wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+            outv[jj][4 * rq + 0] = v[0]; outv[jj][4 * rq + 1] = v[1];
+            outv[jj][4 * rq + 2] = v[2]; outv[jj][4 * rq + 3] = v[3];
+          }
+        });
+        // stage (32 x 64) and store the valid part as row segments
+        const int c0 = 32 * (jb + 2 * g2);             // first channel of this group
+        if (c0 < a.N) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              f32x4 o;
+              o.x = outv[jj][4 * rq + 0]; o.y = outv[jj][4 * rq + 1]; o.z = outv[jj][4 * rq + 2]; o.w = outv[jj][4 * rq + 3];
+              *reinterpret_cast<f32x4*>(stage + tl * PITCH + 32 * jj + 8 * rq + 4 * h) = o;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int ncols = min(64, a.N - c0);         // multiple of 32
+          float* dst = a.y + row0 * a.ldy + (part ? a.N : 0) + c0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int r = i * 4 + (lane >> 4);
+            const int col = (lane & 15) * 4;
+            const f32x4 o = *reinterpret_cast<const f32x4*>(stage + r * PITCH + col);
+            if (r < rows_valid && col < ncols) *reinterpret_cast<f32x4*>(dst + (int64_t)r * a.ldy + col) = o;
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+    });
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+  }
+}
+
+// eligibility of a rows GEMM for the split-precision kernel (otherwise the fp32 kernel runs)
+int wn_gemm_rows16_ok(const WnGemmArgs& a) {
+  if (a.N % 32 != 0 || a.N < 64) return 0;
+  if (!a.vec_out) return 0;
+  for (int s = 0; s < a.nseg; ++s)
+    if (a.seg[s].K % 16 != 0 || !a.seg[s].vec) return 0;
+  if (a.rowbias && (a.ld_rowbias % 4 != 0)) return 0;
+  return 1;
+}
+
+int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* absmax_in0,
+                          const float* absmax_in1, float* absmax_out, hipStream_t s) {
+  if (a.B <= 0 || a.T <= 0 || a.N <= 0) return WN_OK;
+  int nks = 0;
+  for (int i = 0; i < a.nseg; ++i) nks += (a.seg[i].K + 15) / 16;
+  const int64_t tiles = (int64_t)a.B * ((a.T + 31) / 32);
+  int64_t gx = (tiles + 7) / 8;
+  if (gx > 256) gx = 256;
+  const int jt_need = (a.N + 31) / 32;
+  if (jt_need <= 2) {
+    hipLaunchKernelGGL(wn_gemm_rows16_kernel<2>, dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+  } else {
+    // 128 output channels per workgroup column; wider outputs re-read the activations per column
+    hipLaunchKernelGGL(wn_gemm_rows16_kernel<4>, dim3((unsigned)gx, (jt_need + 3) / 4), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+  }
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

@@ -57,6 +57,12 @@ struct WnGemmArgs {
   int32_t vec_out;        // 1: y/addc/aux rows 16-byte aligned, N % 4 == 0
 };
 int wn_launch_gemm_rows(const WnGemmArgs& a, hipStream_t s);
+// split-precision variant: w16 = ONE fp16 hi|lo image of all segments' weights concatenated along k
+// (kind-1 prep, JTtot row tiles); absmax_* are optional device scalars (running max-abs of the
+// B-operand tensors / of the output) used for the exact power-of-two operand scaling
+int wn_gemm_rows16_ok(const WnGemmArgs& a);
+int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* absmax_in0,
+                          const float* absmax_in1, float* absmax_out, hipStream_t s);
 
 // ---------------------------------------------------------------- weight-gradient GEMM
 struct WnWgradArgs {
@@ -125,13 +131,13 @@ int wn_launch_inv_mulaw(const float* y, float* x, int64_t n, hipStream_t s);
 int wn_launch_softmax(const float* logits, float* probs, int64_t rows, int C, hipStream_t s);
 // categorical: Keras sparse CE on clipped probabilities; g_logits may be null (loss only)
 int wn_launch_cat_loss(const float* logits, const int32_t* target, int64_t rows, int C,
-                       float gscale, float* loss_rows, float* g_logits, hipStream_t s);
+                       float gscale, float* loss_rows, float* g_logits, float* absmax_out, hipStream_t s);
 // from_probs variant used by WaveNet.loss_fn(target, pred) on materialised probabilities
 int wn_launch_cat_loss_probs(const float* probs, const int32_t* target, int64_t rows, int C,
                              float* loss_rows, hipStream_t s);
 // kind 1 = logistic, 2 = gaussian
 int wn_launch_mix_loss(const float* pred, const float* y, int64_t rows, int M, int bits, int kind,
-                       float gscale, float* loss_rows, float* g_pred, hipStream_t s);
+                       float gscale, float* loss_rows, float* g_pred, float* absmax_out, hipStream_t s);
 int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scratch, hipStream_t s);
 // deterministic samplers: categorical argmax -> left bin edge; mixtures -> clipped mean
 int wn_launch_sample_det(const float* pred, int64_t rows, int C, int M, int bits, float* out,

@@ -38,12 +38,14 @@ struct ConvInfo {
   int64_t fragB = -1;   // taps images of A[cin][cout]  (backward: A[k][n] = W[tap][k][n])
   int64_t fragF_stride = 0, fragB_stride = 0;
   int64_t frag16 = -1;  // fp16 hi/lo split forward image (all taps concatenated along k), or -1
+  int64_t frag16B = -1; // fp16 split backward-data image A[cin][taps*cout], or -1
 };
 
 struct BlockInfo {
   std::vector<ConvInfo> dil;
   ConvInfo conv1, conv_skip, conv_cond;
   bool has_skip = false, has_cond = false;
+  int64_t g16u = -1;    // fp16 split image [W_r | W_s] (backward: d z) or -1
 };
 
 }  // namespace
@@ -58,6 +60,7 @@ struct wn_plan {
   std::vector<BlockInfo> blocks;
   std::vector<ConvInfo> finals, mapping;
   int64_t frag_skipF = -1;     // A[Sh][N*Dp] image of the folded skip sum
+  int64_t frag16_skipF = -1;   // the same as an fp16 split image, or -1
   int64_t frag_floats = 0;
   std::vector<WnPrepDesc> prep;
   std::vector<WnTensorDesc> tdesc, kdesc;
@@ -154,6 +157,22 @@ void add_image16(wn_plan* p, ConvInfo& c) {
   p->frag_floats += (int64_t)wn_frag16_floats(c.cout, c.taps * c.cin);
 }
 
+// generic fp16 split image made of pieces concatenated along k
+int64_t new_image16(wn_plan* p, int I, int Ktotal) {
+  const int64_t off = p->frag_floats;
+  p->frag_floats += (int64_t)wn_frag16_floats(I, Ktotal);
+  return off;
+}
+void add_piece16(wn_plan* p, int64_t img, int I, int64_t src_off, int KK, int ld, int transpose, int ks_off) {
+  WnPrepDesc d;
+  memset(&d, 0, sizeof(d));
+  d.src_off = src_off; d.dst_off = img; d.I = I; d.KK = KK; d.ld = ld; d.transpose = transpose;
+  d.q_off = ks_off; d.j_off = 0; d.JT = ceil32(I); d.kind = 1;
+  p->prep.push_back(d);
+}
+inline bool m16(int v) { return v > 0 && v % 16 == 0; }
+inline bool m32(int v) { return v >= 64 && v % 32 == 0; }
+
 int ensure_device_tables(wn_plan* p) {
   if (p->d_prep) return WN_OK;
   WN_HIP_CHECK(hipMalloc((void**)&p->d_prep, p->prep.size() * sizeof(WnPrepDesc)));
@@ -195,6 +214,7 @@ struct WsLayout {
   int64_t slab, slab_floats;
   std::vector<int64_t> GU, GH, GO, GF;  // deferred-wgrad mode: per-block g_u, g_h (N+1), g_o; per-final g
   int64_t bslab; int bsplits;           // batched slab [B*bsplits][nparams]
+  int64_t absmax; int n_absmax;         // running max-abs scalars: GF[i] | g_skipsum | GU[b] | GH[b]
   int64_t sum_scratch;
   std::vector<int64_t> M;               // mapping activations [B][w]
   int64_t cb;                           // [N][B][2D]
@@ -258,6 +278,8 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
   L.loss_rows = cv.take(rows);
   L.yt = cv.take(rows);
   L.sum_scratch = cv.take(2048 + 64);
+  L.n_absmax = (int)p->finals.size() + 1 + p->N + (p->N + 1);
+  L.absmax = cv.take(L.n_absmax);
   // conditioning
   if (p->c.cond_inputs > 0) {
     for (size_t j = 0; j < p->mapping.size(); ++j) L.M.push_back(cv.take((int64_t)B * p->mapping[j].cout));
@@ -319,6 +341,13 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 struct Gemm {
   WnGemmArgs a;
+  const float* w16_ = nullptr;
+  const float* am0_ = nullptr;
+  const float* am1_ = nullptr;
+  float* amo_ = nullptr;
+  // split-precision image of ALL segments (concatenated along k); optional max-abs scalars
+  Gemm& w16(const float* img) { w16_ = img; return *this; }
+  Gemm& absmax(const float* in0, const float* in1, float* out) { am0_ = in0; am1_ = in1; amo_ = out; return *this; }
   Gemm(int B, int T, int N, int JTtot) {
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.N = N; a.JTtot = JTtot; a.act = WN_ACT_LINEAR; a.epi = WN_EPI_PLAIN;
@@ -342,6 +371,8 @@ struct Gemm {
     if (a.addc) v = v && (a.ld_addc % 4 == 0) && al16(a.addc);
     if (a.aux) v = v && (a.ld_aux % 4 == 0) && al16(a.aux);
     a.vec_out = v ? 1 : 0;
+    // knob 1 = 1 forces the exact-fp32 MFMA kernels
+    if (w16_ && wn_debug_get(1) != 1 && wn_gemm_rows16_ok(a)) return wn_launch_gemm_rows16(a, w16_, am0_, am1_, amo_, s);
     return wn_launch_gemm_rows(a, s);
   }
 };
@@ -403,6 +434,7 @@ struct BlockPtrs {
   const float* cb;          // [B][2D] per-utterance conditioning bias (model) or null
   bool fused;
   const float* F16d; const float* F16r;   // fp16 split images of the gated conv / conv1, or null
+  const float* G16u; const float* G16x;   // fp16 split images of the backward-data products, or null
 };
 
 struct BlockBufs {
@@ -479,6 +511,8 @@ struct BlockGrads {
   float* dcb;               // [B][2D] per-utterance sums of g_u (model conditioning) or null
   float* slab;
   bool defer;               // weight gradients are computed later by the batched job table
+  const float* am_gxout; const float* am_gskip;   // running max-abs of g_xout / g_skip (or null)
+  float* am_gu; float* am_gx;                      // where to publish max-abs of g_u / g_x (or null)
 };
 
 int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, hipStream_t s) {
@@ -506,6 +540,13 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     if (gm.a.nseg == 0) {
       rc = wn_launch_fill(g.g_u, 0.f, rows * 2 * k.D, s);
     } else {
+      // the [W_r | W_s] image matches the segment list only when both (or, for S == 0, the single) operands exist
+      const bool full = (k.S > 0) ? (g_o && g.g_skip) : true;
+      if (k.G16u && full && k.Cc == 0) {
+        const float* a0 = (g_o == g.g_xout) ? g.am_gxout : (g_o == g.g_skip ? g.am_gskip : g.am_gxout);
+        const float* a1 = (k.S > 0 || g_o == g.g_o_tmp) ? g.am_gskip : nullptr;
+        if (g.am_gu && a0) gm.w16(k.G16u).absmax(a0, a1, g.am_gu);
+      }
       rc = gm.gate_bwd(f.AG, 2 * k.D).run(g.g_u, 2 * k.D, s);
     }
     if (rc) return rc;
@@ -568,6 +609,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
       gcur = dst; gc = k.D;
     } else {
       if (k.residual && g.g_xout) gm.addc(g.g_xout, k.R);
+      if (k.G16x && k.depth == 1 && g.am_gu && g.am_gx) gm.w16(k.G16x).absmax(g.am_gu, nullptr, g.am_gx);
       rc = gm.run(g.g_x, hc, s);
       if (rc) return rc;
     }
@@ -686,6 +728,40 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
       add_image16(p, bi.dil.back());
       add_image16(p, bi.conv1);
     }
+  // split-precision images of the generic contractions (each only when its shape qualifies:
+  // K multiple of 16, N multiple of 32 and >= 64; otherwise the fp32-MFMA kernel runs)
+  for (ConvInfo& c : p->finals) {
+    if (m16(c.cin) && m32(c.cout)) add_image16(p, c);
+    if (m16(c.cout) && m32(c.cin)) {
+      c.frag16B = new_image16(p, c.cin, c.cout);
+      add_piece16(p, c.frag16B, c.cin, p->tensors[c.kernel_t].off, c.cout, c.cout, 0, 0);
+    }
+  }
+  if (p->c.use_skip && m16(p->D) && p->Dp == p->D && m32(p->Sh)) {
+    p->frag16_skipF = new_image16(p, p->Sh, p->N * p->D);
+    for (int b = 0; b < p->N; ++b) {
+      const ConvInfo& src = p->blocks[b].has_skip ? p->blocks[b].conv_skip : p->blocks[b].conv1;
+      add_piece16(p, p->frag16_skipF, p->Sh, p->tensors[src.kernel_t].off, p->D, p->Sh, 1, b * (p->D / 16));
+    }
+  }
+  if (p->LPB == 1 && m32(p->D) && m16(p->R) && (p->S == 0 || m16(p->S))) {
+    for (BlockInfo& bi : p->blocks) {
+      // d z = W_r g_o + W_s g_skip : image [W_r | W_s], I = D
+      bi.g16u = new_image16(p, p->D, p->R + p->S);
+      add_piece16(p, bi.g16u, p->D, p->tensors[bi.conv1.kernel_t].off, p->R, p->R, 0, 0);
+      if (bi.has_skip) add_piece16(p, bi.g16u, p->D, p->tensors[bi.conv_skip.kernel_t].off, p->S, p->S, 0, p->R / 16);
+    }
+  }
+  if (p->LPB == 1 && m32(p->R) && m16(2 * p->D)) {
+    for (BlockInfo& bi : p->blocks) {
+      // d x = sum_tap W_tap g_u[t + shift] : image of KS pieces A[R][2D], I = R
+      ConvInfo& c = bi.dil[0];
+      c.frag16B = new_image16(p, p->R, p->KS * 2 * p->D);
+      for (int t = 0; t < p->KS; ++t)
+        add_piece16(p, c.frag16B, p->R, p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D, 2 * p->D,
+                    2 * p->D, 0, t * (2 * p->D / 16));
+    }
+  }
   return p;
 }
 
@@ -782,6 +858,8 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   k.Cc = 0; k.cond = nullptr; k.cb = nullptr;
   k.fused = p->fused_ok;
   if (p->fused16_ok && p->LPB == 1) { k.F16d = fragbase + bi.dil.back().frag16; k.F16r = fragbase + bi.conv1.frag16; }
+  if (bi.g16u >= 0) k.G16u = fragbase + bi.g16u;
+  if (p->LPB == 1 && bi.dil[0].frag16B >= 0) k.G16x = fragbase + bi.dil[0].frag16B;
   return k;
 }
 
@@ -869,6 +947,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   const float* hin;
   if (p->c.use_skip) {
     rc = Gemm(B, T, p->Sh, ceil32(p->Sh)).seg(ws + L.Z, p->N * p->Dp, p->N * p->Dp, 0, fragbase + p->frag_skipF)
+             .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
              .bias(ws + L.bias_sum).run(ws + L.skipsum, p->Sh, s);
     if (rc) return rc;
     hin = ws + L.skipsum;
@@ -882,6 +961,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     const bool last = (i + 1 == p->finals.size());
     float* dst = last ? ws + L.logits : ws + L.HA[i];
     rc = Gemm(B, T, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
+             .w16(c.frag16 >= 0 ? fragbase + c.frag16 : nullptr)
              .bias(params + p->tensors[c.bias_t].off).act(last ? WN_ACT_LINEAR : p->c.activation).run(dst, c.cout, s);
     if (rc) return rc;
     hin = dst; hc = c.cout;
@@ -899,7 +979,7 @@ __global__ void wn_shift_split_kernel(const float* x_full, int B, int T, float* 
 }
 
 int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float* ws, const WsLayout& L,
-               float* loss_out, hipStream_t s) {
+               float* loss_out, float* absmax_out, hipStream_t s) {
   const int64_t rows = (int64_t)B * T;
   const float gscale = 1.0f / (float)global_batch;     // compute_average_loss, src/model.py:328-329
   int rc;
@@ -908,10 +988,10 @@ int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float
     rc = wn_launch_quantize(ws + L.yt, reinterpret_cast<int32_t*>(ws + L.target), rows, p->c.bits, s);
     if (rc) return rc;
     rc = wn_launch_cat_loss(ws + L.logits, reinterpret_cast<const int32_t*>(ws + L.target), rows, p->Cout,
-                            gscale, ws + L.loss_rows, g_logits, s);
+                            gscale, ws + L.loss_rows, g_logits, absmax_out, s);
   } else {
     rc = wn_launch_mix_loss(ws + L.logits, ws + L.yt, rows, p->c.num_mixtures, p->c.bits,
-                            p->c.head == WN_HEAD_LOGISTIC ? 1 : 2, gscale, ws + L.loss_rows, g_logits, s);
+                            p->c.head == WN_HEAD_LOGISTIC ? 1 : 2, gscale, ws + L.loss_rows, g_logits, absmax_out, s);
   }
   if (rc) return rc;
   return wn_launch_sum(ws + L.loss_rows, rows, gscale, loss_out, ws + L.sum_scratch, s);
@@ -1012,7 +1092,7 @@ extern "C" int wn_eval_loss(wn_plan* p, const float* params, const float* x_full
                      x_full, B, T, inputs, workspace + L.yt);
   int rc = forward_core(p, params, inputs, true, cond, B, T, false, workspace, L, s);
   if (rc) return rc;
-  rc = loss_stage(p, B, T, global_batch > 0 ? global_batch : B, false, workspace, L, loss_out, s);
+  rc = loss_stage(p, B, T, global_batch > 0 ? global_batch : B, false, workspace, L, loss_out, nullptr, s);
   if (rc) return rc;
   if (pred_out) {
     if (p->c.head == WN_HEAD_CATEGORICAL) return wn_launch_softmax(workspace + L.logits, pred_out, rows, p->Cout, s);
@@ -1038,7 +1118,15 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
                      x_full, B, T, inputs, ws + L.yt);
   int rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
   if (rc) return rc;
-  rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, s);
+  // running max-abs scalars of the gradient tensors (operand scaling of the split-precision GEMMs)
+  float* am = ws + L.absmax;
+  const int nf = (int)p->finals.size();
+  auto am_GF = [&](int i) { return am + i; };
+  float* am_gskip = am + nf;
+  auto am_GU = [&](int b) { return am + nf + 1 + b; };
+  auto am_GH = [&](int b) { return am + nf + 1 + p->N + b; };
+  WN_HIP_CHECK(hipMemsetAsync(am, 0, L.n_absmax * sizeof(float), s));
+  rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s);
   if (rc) return rc;
   if (pred_out) {
     if (p->c.head == WN_HEAD_CATEGORICAL) rc = wn_launch_softmax(ws + L.logits, pred_out, rows, p->Cout, s);
@@ -1079,6 +1167,8 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       gm.seg(ws + L.GF[i], c.cout, c.cout, 0, fragbase + c.fragB);
       float* dst = (i == 0) ? head_out : ws + L.GF[i - 1];
       if (i > 0) gm.dact(ws + L.HA[i - 1], c.cin, p->c.activation);
+      if (c.frag16B >= 0)
+        gm.w16(fragbase + c.frag16B).absmax(am_GF(i), nullptr, i > 0 ? am_GF(i - 1) : (p->c.use_skip ? am_gskip : am_GH(p->N)));
       rc = gm.run(dst, c.cin, s);
       if (rc) return rc;
     }
@@ -1106,6 +1196,9 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       bg.g_x = ws + L.GH[b];
       bg.dcb = bi.has_cond ? ws + L.dcb : nullptr;
       bg.slab = slab;
+      bg.am_gxout = bg.g_xout ? am_GH(b + 1) : nullptr;
+      bg.am_gskip = g_skip ? am_gskip : nullptr;
+      bg.am_gu = am_GU(b); bg.am_gx = am_GH(b);
       rc = block_backward(k, f, bg, s);
       if (rc) return rc;
       if (p->S == 0 && bg.g_xout == nullptr && g_skip) {
@@ -1560,7 +1653,7 @@ extern "C" int wn_loss_fn(int32_t head, const void* target, const float* pred, i
     return wn_launch_cat_loss_probs(pred, (const int32_t*)target, rows, C, loss_rows, s);
   if (head == WN_HEAD_LOGISTIC || head == WN_HEAD_GAUSSIAN)
     return wn_launch_mix_loss(pred, (const float*)target, rows, num_mixtures, bits, head == WN_HEAD_LOGISTIC ? 1 : 2,
-                              1.0f, loss_rows, nullptr, s);
+                              1.0f, loss_rows, nullptr, nullptr, s);
   wn_set_error("Loss %d not implemented.", head);
   return WN_E_UNSUPPORTED;
 }
