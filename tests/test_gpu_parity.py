@@ -441,3 +441,32 @@ def test_generate_errors():
   with pytest.raises(ValueError, match='Loss must be set in the model init function'):
     m2.compile(loss='mse')
   assert abs(m2.compute_receptive_field(16000) - m2.receptive_field / 16000) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------
+# queued (ring-buffer) generation == sliding window, index for index (README.md:16 TODO of the
+# reference; A/B hook src/callbacks.py:58-68)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,det', [('cat_noskipch', True), ('cat_small_fused', True), ('cat_r64', True),
+                                      ('mol', True), ('cond', True), ('cat_odd_composed', True),
+                                      ('cat_k3', True), ('cat_noskip_nores', True), ('cat_small_fused', False)])
+def test_queued_generation_equals_naive(name, det):
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=7, bias_range=0.3, **kw)
+  rf = model.receptive_field
+  B, n = 3, 25
+  w = O.synthetic_waveform(B, rf, seed=4).to(dev())
+  cond = None
+  if kw.get('conditioning') is not None:
+    cond = torch.rand(B, kw['cond_inputs'], generator=torch.Generator().manual_seed(2)).to(dev())
+  naive = model.generate(n, condition=cond, sample=w, use_queues=False, deterministic=det)
+  queued = model.generate(n, condition=cond, sample=w, use_queues=True, deterministic=det)
+  assert queued.shape == (B, n, 1)
+  assert torch.equal(naive, queued), (naive - queued).abs().max()
+
+
+def test_queued_generation_needs_depth_one():
+  kw = dict(MODEL_CASES['cat_lpb3'])
+  ocfg, params, model = make_pair(seed=7, **kw)
+  with pytest.raises(NotImplementedError):
+    model.generate(3, batch_size=1, use_queues=True, deterministic=True)

@@ -1,0 +1,21 @@
+"""Generation speed (the reference prints 'Speed of generation was ... samples/s', train.py:253-261):
+naive sliding window vs queued ring buffers on BASELINE configs[1] weights, batch B."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wavenets_amd import WaveNet
+import bench
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device('cuda', 0)
+m = WaveNet(**bench.CFG2, device=dev)
+w = (torch.rand(B, m.receptive_field, 1, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+for name, queued, n in (('naive', False, 20), ('queued', True, 400)):
+  m.generate(3, sample=w, use_queues=queued, deterministic=True)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  out = m.generate(n, sample=w, use_queues=queued, deterministic=True)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  print(f'{name}: B={B} {n} samples/utterance in {dt:.3f} s -> {n / dt:.1f} samples/s per utterance, '
+        f'{B * n / dt:.1f} samples/s aggregate, {dt / n * 1e3:.3f} ms/step')

@@ -108,6 +108,7 @@ struct WnLayerFwdArgs {
   float* z_out; int32_t ldz;   // gated activations, row stride ldz, or null
   float* ag_out;         // [B*T][2D] saved tanh | sigmoid, or null
   const float* res;      // residual source [B*T][R] when it is not the conv input (depth > 1), or null
+  const float* xt[3];    // queued generation: tap j reads rows of xt[j] (no time shift) instead of x; or null
   int32_t B, T, R, D, KS, dilation, residual;
 };
 int wn_layer_fwd_supported(int R, int D, int KS);

@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
   bool xvalid[KS];
 #pragma unroll
   for (int tap = 0; tap < KS; ++tap) {
-    const int ts = t - (KS - 1 - tap) * a.dilation;
+    const int ts = a.xt[tap] ? t : t - (KS - 1 - tap) * a.dilation;
     xvalid[tap] = tin && ts >= 0;
-    const float* xrow = a.x + ((int64_t)b * a.T + (xvalid[tap] ? ts : 0)) * R + 4 * h;
+    const float* xrow = (a.xt[tap] ? a.xt[tap] : a.x) + ((int64_t)b * a.T + (xvalid[tap] ? ts : 0)) * R + 4 * h;
 #pragma unroll
     for (int q = 0; q < QR; ++q) {
       if constexpr (VAR & 16) xq[tap][q] = f32x4{0.1f * q, 0.2f, 0.3f, 0.05f * lane};

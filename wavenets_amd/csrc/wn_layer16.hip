@@ -116,9 +116,9 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
     bool xvalid[KS];
 #pragma unroll
     for (int tap = 0; tap < KS; ++tap) {
-      const int ts = t - (KS - 1 - tap) * a.dilation;
+      const int ts = a.xt[tap] ? t : t - (KS - 1 - tap) * a.dilation;
       xvalid[tap] = tin && ts >= 0;
-      const float* xrow = a.x + ((int64_t)b * a.T + (xvalid[tap] ? ts : 0)) * R + 4 * h;
+      const float* xrow = (a.xt[tap] ? a.xt[tap] : a.x) + ((int64_t)b * a.T + (xvalid[tap] ? ts : 0)) * R + 4 * h;
 #pragma unroll
       for (int q = 0; q < QR; ++q) xq[tap][q] = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
     }

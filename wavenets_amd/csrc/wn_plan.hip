@@ -445,6 +445,7 @@ struct BlockBufs {
   float* Z; int ldz;        // gated activations
   float* O;                 // [rows][R] pre-residual output or null
   float* x_out;             // [rows][R]
+  const float* xt[3];       // queued generation: per-tap input rows (no time shift), or null
 };
 
 int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
@@ -469,13 +470,17 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     a.bias_d = k.bd[li]; a.bias_r = k.br; a.cb = k.cb;
     a.x_out = f.x_out; a.o_out = f.O; a.z_out = f.Z; a.ldz = f.ldz; a.ag_out = f.AG;
     a.res = (k.depth > 1) ? f.x : nullptr;
+    a.xt[0] = f.xt[0]; a.xt[1] = f.xt[1]; a.xt[2] = f.xt[2];
     a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
     return use16 ? wn_launch_layer_fwd_f16(a, s) : wn_launch_layer_fwd(a, s);
   }
   // composed path: u -> gate -> 1x1
   {
     Gemm g(k.B, k.T, 2 * k.D, ceil32(2 * k.D));
-    for (int t = 0; t < k.KS; ++t) g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[li], k.Fd[li] + t * k.Fd_stride[li]);
+    for (int t = 0; t < k.KS; ++t) {
+      if (f.xt[t]) g.seg(f.xt[t], hc, hc, 0, k.Fd[li] + t * k.Fd_stride[li]);
+      else g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[li], k.Fd[li] + t * k.Fd_stride[li]);
+    }
     if (k.Cc > 0) g.seg(k.cond, k.Cc, k.Cc, 0, k.Fc);
     g.bias(k.bd[li]);
     if (k.cb) g.rowbias(k.cb, 2 * k.D);
@@ -870,8 +875,35 @@ struct FwdCtx {
 };
 
 // everything up to the logits; training keeps every activation
+// queued generation state: per block a ring of its most recent input rows, [slot][B][R]
+struct GenRings {
+  float* xin;                  // [KS][B] raw samples
+  std::vector<float*> h;       // per block: [nslots_b][B][R]
+  std::vector<int> nslots;
+};
+
+__global__ void wn_ring_capture_kernel(const float* src, int B, int T, int C, int nslots, float* ring) {
+  // ring[(t % nslots)][b][c] = src[b][t][c] for the last nslots time steps
+  const int64_t n = (int64_t)nslots * B * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int b = (int)((i / C) % B);
+    const int k = (int)(i / ((int64_t)C * B));
+    const int t = T - nslots + k;
+    if (t >= 0) ring[((int64_t)(t % nslots) * B + b) * C + c] = src[((int64_t)b * T + t) * C + c];
+  }
+}
+
+int ring_capture(const float* src, int B, int T, int C, int nslots, float* ring, hipStream_t s) {
+  const int64_t n = (int64_t)nslots * B * C;
+  hipLaunchKernelGGL(wn_ring_capture_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s,
+                     src, B, T, C, nslots, ring);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
 int forward_core(wn_plan* p, const float* params, const float* x, bool prep, const float* cond, int B,
-                 int T, bool training, float* ws, const WsLayout& L, hipStream_t s) {
+                 int T, bool training, float* ws, const WsLayout& L, hipStream_t s, const GenRings* rings = nullptr) {
   int rc = ensure_device_tables(p);
   if (rc) return rc;
   const int64_t rows = (int64_t)B * T;
@@ -917,6 +949,11 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
       g.seg(x, 1, 1, (p->KS - 1 - t), fragbase + p->causal.fragF + t * p->causal.fragF_stride);
     rc = g.bias(params + p->tensors[p->causal.bias_t].off).run(ws + L.H[0], p->R, s);
     if (rc) return rc;
+    if (rings) {
+      rc = ring_capture(x, B, T, 1, p->KS, rings->xin, s);
+      if (!rc) rc = ring_capture(ws + L.H[0], B, T, p->R, rings->nslots[0], rings->h[0], s);
+      if (rc) return rc;
+    }
   }
   if (p->Dp != p->D) {
     rc = wn_launch_fill(ws + L.Z, 0.f, rows * p->N * p->Dp, s);
@@ -941,6 +978,10 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = block_forward(k, f, s);
     if (rc) return rc;
     if (prof) { (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s); p->prof_used += 2; }
+    if (rings && b + 1 < p->N) {
+      rc = ring_capture(f.x_out, B, T, p->R, rings->nslots[b + 1], rings->h[b + 1], s);
+      if (rc) return rc;
+    }
   }
   // skip sum folded into one contraction over all blocks' gated activations (src/model.py:235-236
   // with src/layers.py:216-219), or the last block output when use_skip is False
@@ -1360,44 +1401,184 @@ __global__ void wn_gather_last_kernel(const float* logits, int B, int RF, int C,
 
 }  // namespace
 
+namespace {
+
+struct GenLayout {
+  int64_t prime;                       // priming forward workspace (make_layout(B, RF, inference))
+  int64_t win0, win1, last, lastp, samp;
+  int64_t xin;                         // [KS][B]
+  std::vector<int64_t> ring;           // per block [nslots][B][R]
+  std::vector<int> nslots;
+  int64_t Zrow, skiprow, hrow0, hrow1, dummy;   // per-step rows
+  std::vector<int64_t> HArow;
+  int64_t total;
+};
+
+GenLayout gen_layout(const wn_plan* p, int B, bool queued) {
+  GenLayout G;
+  Carver cv;
+  const int RF = wn_plan_receptive_field(p);
+  G.prime = cv.take(make_layout(p, B, RF, false).total);
+  G.win0 = cv.take((int64_t)B * RF);
+  G.win1 = cv.take((int64_t)B * RF);
+  G.last = cv.take((int64_t)B * p->Cout);
+  G.lastp = cv.take((int64_t)B * p->Cout);
+  G.samp = cv.take(B);
+  G.xin = G.Zrow = G.skiprow = G.hrow0 = G.hrow1 = G.dummy = 0;
+  if (queued) {
+    G.xin = cv.take((int64_t)p->KS * B);
+    for (int b = 0; b < p->N; ++b) {
+      const int ns = (p->KS - 1) * p->blocks[b].dil.back().dil + 1;
+      G.nslots.push_back(ns);
+      G.ring.push_back(cv.take((int64_t)ns * B * p->R));
+    }
+    G.Zrow = cv.take((int64_t)B * p->N * p->Dp);
+    G.skiprow = cv.take((int64_t)B * p->Hin);
+    G.hrow0 = cv.take((int64_t)B * p->R);
+    G.hrow1 = cv.take((int64_t)B * 2 * p->D);
+    G.dummy = cv.take((int64_t)B * p->R);
+    for (size_t i = 0; i + 1 < p->finals.size(); ++i) G.HArow.push_back(cv.take((int64_t)B * p->finals[i].cout));
+  }
+  G.total = cv.pos;
+  return G;
+}
+
+__global__ void wn_gen_emit_kernel(const float* samp, int B, float* out, int length, int step, float* xin_slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  out[(int64_t)b * length + step] = samp[b];
+  if (xin_slot) xin_slot[b] = samp[b];
+}
+
+// sample from the logits rows [B][Cout] (src/model.py:253-255 + sample_waveform)
+int sample_rows(wn_plan* p, const float* logits_rows, int B, bool deterministic, uint64_t seed, uint64_t step,
+                float* probs_tmp, float* samp, hipStream_t s) {
+  const float* pred = logits_rows;
+  int rc;
+  if (p->c.head == WN_HEAD_CATEGORICAL) {
+    rc = wn_launch_softmax(logits_rows, probs_tmp, B, p->Cout, s);     // the model output is probabilities
+    if (rc) return rc;
+    pred = probs_tmp;
+  }
+  if (deterministic) return wn_launch_sample_det(pred, B, p->Cout, p->c.num_mixtures, p->c.bits, samp, s);
+  return wn_launch_sample_rand(pred, B, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, seed, step, samp, s);
+}
+
+}  // namespace
+
 extern "C" int64_t wn_generate_workspace_floats(const wn_plan* p, int32_t B, int32_t queued) {
   if (!p || B < 1) return 0;
-  (void)queued;
-  const int RF = wn_plan_receptive_field(p);
-  return make_layout(p, B, RF, false).total + 2 * align64((int64_t)B * RF) + 2 * align64((int64_t)B * p->Cout) + align64(B);
+  return gen_layout(p, B, queued != 0).total;
 }
 
 extern "C" int wn_generate(wn_plan* p, const float* params, const float* window, const float* cond, int32_t B,
                            int32_t length, int32_t deterministic, int32_t queued, uint64_t seed, float* out,
                            float* workspace, int64_t ws_floats, void* stream) {
   if (!p || !params || !window || !out || !workspace || B < 1 || length < 0) { wn_set_error("generate: bad arguments"); return WN_E_INVALID; }
-  if (queued) { wn_set_error("generate: queued generation is not built yet"); return WN_E_UNSUPPORTED; }
+  if (queued && p->LPB != 1) {
+    // same limitation as the reference's own design (README.md:16, src/layers.py:226-290)
+    wn_set_error("queued generation supports one dilated convolution per block only");
+    return WN_E_UNSUPPORTED;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int RF = wn_plan_receptive_field(p);
+  const GenLayout G = gen_layout(p, B, queued != 0);
+  if (ws_floats < G.total) { wn_set_error("generate: workspace too small"); return WN_E_INVALID; }
+  if (length == 0) return WN_OK;
+  float* pws = workspace + G.prime;
   const WsLayout L = make_layout(p, B, RF, false);
-  if (ws_floats < wn_generate_workspace_floats(p, B, 0)) { wn_set_error("generate: workspace too small"); return WN_E_INVALID; }
-  float* win[2] = {workspace + L.total, workspace + L.total + align64((int64_t)B * RF)};
-  float* last = win[1] + align64((int64_t)B * RF);
-  float* lastp = last + align64((int64_t)B * p->Cout);
-  float* samp = lastp + align64((int64_t)B * p->Cout);
+  float* win[2] = {workspace + G.win0, workspace + G.win1};
+  float* last = workspace + G.last;
+  float* lastp = workspace + G.lastp;
+  float* samp = workspace + G.samp;
   WN_HIP_CHECK(hipMemcpyAsync(win[0], window, (int64_t)B * RF * sizeof(float), hipMemcpyDeviceToDevice, s));
-  const int M = p->c.num_mixtures;
-  for (int step = 0; step < length; ++step) {
-    int rc = forward_core(p, params, win[step & 1], step == 0, cond, B, RF, false, workspace, L, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(wn_gather_last_kernel, dim3((B * p->Cout + 255) / 256), dim3(256), 0, s,
-                       workspace + L.logits, B, RF, p->Cout, last);
-    const float* pred = last;
-    if (p->c.head == WN_HEAD_CATEGORICAL) {
-      rc = wn_launch_softmax(last, lastp, B, p->Cout, s);     // the model output is probabilities
+  int rc;
+
+  if (!queued) {
+    // ---- naive sliding window: one full forward over the window per sample (src/model.py:296-305) ----
+    for (int step = 0; step < length; ++step) {
+      rc = forward_core(p, params, win[step & 1], step == 0, cond, B, RF, false, pws, L, s);
       if (rc) return rc;
-      pred = lastp;
+      hipLaunchKernelGGL(wn_gather_last_kernel, dim3((B * p->Cout + 255) / 256), dim3(256), 0, s, pws + L.logits, B, RF, p->Cout, last);
+      rc = sample_rows(p, last, B, deterministic != 0, seed, (uint64_t)step, lastp, samp, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(wn_gen_shift_kernel, dim3((B * RF + 255) / 256), dim3(256), 0, s, win[step & 1], samp, B, RF,
+                         win[(step + 1) & 1], out, length, step);
+      WN_HIP_CHECK(hipGetLastError());
     }
-    if (deterministic) rc = wn_launch_sample_det(pred, B, p->Cout, M, p->c.bits, samp, s);
-    else rc = wn_launch_sample_rand(pred, B, p->Cout, M, p->c.bits, p->c.head, seed, (uint64_t)step, samp, s);
+    return WN_OK;
+  }
+
+  // ---- queued: prime the per-block rings with one forward over the window, then one time step per
+  //      sample with rows = utterances; every kernel and every per-row operation order is the one
+  //      the sliding window uses, so the results are identical ----
+  GenRings R;
+  R.xin = workspace + G.xin;
+  for (int b = 0; b < p->N; ++b) { R.h.push_back(workspace + G.ring[b]); R.nslots.push_back(G.nslots[b]); }
+  rc = forward_core(p, params, win[0], true, cond, B, RF, false, pws, L, s, &R);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wn_gather_last_kernel, dim3((B * p->Cout + 255) / 256), dim3(256), 0, s, pws + L.logits, B, RF, p->Cout, last);
+  rc = sample_rows(p, last, B, deterministic != 0, seed, 0, lastp, samp, s);
+  if (rc) return rc;
+  // sample 0 is x[RF]; it becomes the network input at time tau = RF
+  hipLaunchKernelGGL(wn_gen_emit_kernel, dim3((B + 255) / 256), dim3(256), 0, s, samp, B, out, length, 0,
+                     R.xin + (int64_t)(RF % p->KS) * B);
+  const float* fragbase = pws + L.frag;
+  float* Zrow = workspace + G.Zrow;
+  for (int step = 1; step < length; ++step) {
+    const int64_t tau = (int64_t)RF + step - 1;        // time of the newest known sample
+    // input causal conv on [x[tau-(KS-1)], ..., x[tau]]  ->  block 0's ring slot tau
+    {
+      Gemm g(B, 1, p->R, ceil32(p->R));
+      for (int t = 0; t < p->KS; ++t)
+        g.seg(R.xin + (int64_t)((tau - (p->KS - 1 - t)) % p->KS) * B, 1, 1, 0,
+              fragbase + p->causal.fragF + t * p->causal.fragF_stride);
+      rc = g.bias(params + p->tensors[p->causal.bias_t].off).run(R.h[0] + (int64_t)(tau % R.nslots[0]) * B * p->R, p->R, s);
+      if (rc) return rc;
+    }
+    for (int b = 0; b < p->N; ++b) {
+      BlockPtrs k = block_ptrs(p, b, params, fragbase, B, 1);
+      if (p->c.cond_inputs > 0) k.cb = pws + L.cb + (int64_t)b * B * 2 * p->D;
+      const int d = p->blocks[b].dil.back().dil;
+      BlockBufs f;
+      memset(&f, 0, sizeof(f));
+      for (int t = 0; t < p->KS; ++t)
+        f.xt[t] = R.h[b] + (int64_t)((tau - (int64_t)(p->KS - 1 - t) * d) % R.nslots[b]) * B * p->R;
+      f.x = f.xt[p->KS - 1];
+      f.U = workspace + G.hrow1;
+      f.AG = nullptr;
+      f.Z = Zrow + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+      f.O = nullptr;
+      f.x_out = (b + 1 < p->N) ? R.h[b + 1] + (int64_t)(tau % R.nslots[b + 1]) * B * p->R
+                               : (p->c.use_skip ? workspace + G.dummy : workspace + G.hrow0);
+      rc = block_forward(k, f, s);
+      if (rc) return rc;
+    }
+    const float* hin;
+    if (p->c.use_skip) {
+      rc = Gemm(B, 1, p->Sh, ceil32(p->Sh)).seg(Zrow, p->N * p->Dp, p->N * p->Dp, 0, fragbase + p->frag_skipF)
+               .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
+               .bias(pws + L.bias_sum).run(workspace + G.skiprow, p->Sh, s);
+      if (rc) return rc;
+      hin = workspace + G.skiprow;
+    } else {
+      hin = workspace + G.hrow0;
+    }
+    int hc = p->Hin;
+    for (size_t i = 0; i < p->finals.size(); ++i) {
+      const ConvInfo& c = p->finals[i];
+      const bool lastl = (i + 1 == p->finals.size());
+      float* dst = lastl ? last : workspace + G.HArow[i];
+      rc = Gemm(B, 1, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
+               .w16(c.frag16 >= 0 ? fragbase + c.frag16 : nullptr)
+               .bias(params + p->tensors[c.bias_t].off).act(lastl ? WN_ACT_LINEAR : p->c.activation).run(dst, c.cout, s);
+      if (rc) return rc;
+      hin = dst; hc = c.cout;
+    }
+    rc = sample_rows(p, last, B, deterministic != 0, seed, (uint64_t)step, lastp, samp, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(wn_gen_shift_kernel, dim3((B * RF + 255) / 256), dim3(256), 0, s, win[step & 1], samp, B, RF,
-                       win[(step + 1) & 1], out, length, step);
+    hipLaunchKernelGGL(wn_gen_emit_kernel, dim3((B + 255) / 256), dim3(256), 0, s, samp, B, out, length, step,
+                       R.xin + (int64_t)((tau + 1) % p->KS) * B);
     WN_HIP_CHECK(hipGetLastError());
   }
   return WN_OK;
