@@ -395,6 +395,118 @@ __device__ __forceinline__ void wn_wgrad_body(const WnWgUnit& a) {
   }
 }
 
+// Split-precision form of the same unit (fp16 hi/lo, 3 products, fp32 accumulate) on
+// v_mfma_f32_32x32x16_f16 with time as the MFMA K dimension: lane (c = l&31, h = l>>5) holds 8
+// consecutive time steps t0 + 8h .. +7 of its channel for each operand tile; loads stay one dword per
+// lane, 128 contiguous bytes per half wave.  gsc / inv_gsc: exact power-of-two scaling of the
+// gradient operand (running max-abs of its tensor), undone on the accumulators.
+typedef _Float16 wg_h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void wn_wgrad_body16(const WnWgUnit& a, float gsc, float inv_gsc) {
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & 31, h = lane >> 5;
+  const int k0 = a.k0, n0 = a.n0, r0 = a.r0, r1 = a.r1;
+
+  f32x16 acc[WG_TM][WG_TN];
+#pragma unroll
+  for (int i = 0; i < WG_TM; ++i)
+#pragma unroll
+    for (int j = 0; j < WG_TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[WG_TN];
+#pragma unroll
+  for (int j = 0; j < WG_TN; ++j) bsum[j] = 0.f;
+
+  bool kin[WG_TM], nin[WG_TN];
+#pragma unroll
+  for (int i = 0; i < WG_TM; ++i) kin[i] = (k0 + 32 * i + tl) < a.K;
+#pragma unroll
+  for (int j = 0; j < WG_TN; ++j) nin[j] = (n0 + 32 * j + tl) < a.N;
+  const float* xbase = a.x + (int64_t)a.b * a.T * a.ldx + k0 + tl;
+  const float* gbase = a.g + (int64_t)a.b * a.T * a.ldg + n0 + tl;
+
+  // one chunk = 16 time steps; raw fp32 operands of the next chunk are in flight during the MFMAs
+  auto load_chunk = [&](int tt0, float (&av)[WG_TM][8], float (&bv)[WG_TN][8]) {
+    const int tb = tt0 + 8 * h;
+    const float* px = xbase + (int64_t)(tb - a.shift) * a.ldx;
+    const float* pg = gbase + (int64_t)tb * a.ldg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = tb + e;
+      const int ts = t - a.shift;
+      const bool tv = t < r1;
+      const bool xv = tv && ts >= 0 && ts < a.T;
+#pragma unroll
+      for (int i = 0; i < WG_TM; ++i) av[i][e] = (xv && kin[i]) ? px[(int64_t)e * a.ldx + 32 * i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < WG_TN; ++j) bv[j][e] = (tv && nin[j]) ? pg[(int64_t)e * a.ldg + 32 * j] : 0.f;
+    }
+  };
+  auto compute_chunk = [&](const float (&av)[WG_TM][8], const float (&bv)[WG_TN][8]) {
+    wg_h8 ah[WG_TM], al[WG_TM];
+#pragma unroll
+    for (int i = 0; i < WG_TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)av[i][e];
+        ah[i][e] = hh;
+        al[i][e] = (_Float16)(av[i][e] - (float)hh);
+      }
+#pragma unroll
+    for (int j = 0; j < WG_TN; ++j) {
+      wg_h8 bh, bl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bsum[j] += bv[j][e];
+        const float v = bv[j][e] * gsc;
+        const _Float16 hh = (_Float16)v;
+        bh[e] = hh;
+        bl[e] = (_Float16)(v - (float)hh);
+      }
+#pragma unroll
+      for (int i = 0; i < WG_TM; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  {
+    float av0[WG_TM][8], bv0[WG_TN][8], av1[WG_TM][8], bv1[WG_TN][8];
+    int tt = r0;
+    if (tt < r1) load_chunk(tt, av0, bv0);
+    for (; tt < r1; tt += 32) {
+      if (tt + 16 < r1) load_chunk(tt + 16, av1, bv1);
+      compute_chunk(av0, bv0);
+      if (tt + 16 < r1) {
+        if (tt + 32 < r1) load_chunk(tt + 32, av0, bv0);
+        compute_chunk(av1, bv1);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < WG_TM; ++i)
+#pragma unroll
+    for (int j = 0; j < WG_TN; ++j) {
+      const int n = n0 + 32 * j + tl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + 32 * i + wn_drow(r, h);
+        if (k < a.K && n < a.N) a.out[(int64_t)k * a.out_ld + n] = acc[i][j][r] * inv_gsc;
+      }
+    }
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < WG_TN; ++j) {
+      const float tot = bsum[j] + __shfl_xor(bsum[j], 32);
+      const int n = n0 + 32 * j + tl;
+      if (h == 0 && n < a.N) a.bias[n] = tot;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void wn_wgrad_kernel(WnWgradArgs a, int nkb, int nnb) {
   const int wave = threadIdx.x >> 6;
   const int nsplit = a.B * a.splits_per_b;
@@ -415,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_kernel(WnWgradArgs a, int nkb
 
 // Batched form: a table of jobs (one per K-block x N-block of some dW), every job split over
 // time; partial results go to slab[split][P] laid out exactly like the flat gradient buffer.
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void wn_wgrad_batched_kernel(const WnWgJob* jobs, float* ws, float* slab,
                                                                   int64_t P, int B, int T, int splits_per_b) {
   const int wave = threadIdx.x >> 6;
@@ -432,15 +545,35 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_batched_kernel(const WnWgJob*
   float* row = slab + (int64_t)split * P;
   u.out = row + j.out_off; u.out_ld = j.N;
   u.bias = j.bias_off >= 0 ? row + j.bias_off : nullptr;
-  wn_wgrad_body(u);
+  if constexpr (F16) {
+    float gsc = 1.0f, inv = 1.0f;
+    if (j.gmax_off >= 0) {
+      const float m = ws[j.gmax_off];
+      if (m > 0.f && m < 3.0e38f) {
+        int e;
+        (void)frexpf(m, &e);
+        e = max(-100, min(100, e));
+        gsc = ldexpf(1.0f, -e);
+        inv = ldexpf(1.0f, e);
+      }
+    }
+    wn_wgrad_body16(u, gsc, inv);
+  } else {
+    wn_wgrad_body(u);
+  }
 }
 
 int wn_launch_wgrad_batched(const WnWgJob* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
                             int splits_per_b, hipStream_t s) {
   if (njobs <= 0) return WN_OK;
   const int nsplit = B * splits_per_b;
-  hipLaunchKernelGGL(wn_wgrad_batched_kernel, dim3((nsplit + 3) / 4, njobs), dim3(256), 0, s, d_jobs, ws, slab, P, B,
-                     T, splits_per_b);
+  // knob 1 = 1 forces exact-fp32 MFMA; knob 3 = 1 keeps the weight gradients alone on fp32
+  if (wn_debug_get(1) == 1 || wn_debug_get(3) == 1)
+    hipLaunchKernelGGL(wn_wgrad_batched_kernel<false>, dim3((nsplit + 3) / 4, njobs), dim3(256), 0, s, d_jobs, ws, slab, P,
+                       B, T, splits_per_b);
+  else
+    hipLaunchKernelGGL(wn_wgrad_batched_kernel<true>, dim3((nsplit + 3) / 4, njobs), dim3(256), 0, s, d_jobs, ws, slab, P,
+                       B, T, splits_per_b);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

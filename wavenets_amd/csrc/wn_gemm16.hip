@@ -44,6 +44,97 @@ struct WnG16 {
   static constexpr int LDS_BYTES = 2 * CHUNK_BYTES + WAVES * STAGE_BYTES;   // 135168
 };
 
+// epilogue shared by the streamed and the resident kernels: bias / row bias / residual / activation
+// (or activation derivative, or gate derivative) in registers, then staged full-row stores
+template <int JT, int PITCH>
+__device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&acc)[JT], float inv_sc, int jb, int b,
+                                                int t, int64_t row0, int rows_valid, float* stage, int lane,
+                                                float& wmax) {
+  const int tl = lane & 31, h = lane >> 5;
+  {
+    // ---- epilogue in registers (D layout), then staged row stores, 64 channels at a time ----
+    const int64_t row = row0 + tl;
+    const bool tin = t < a.T;
+    // GATE_BWD produces two outputs per accumulator; they are staged one after the other
+    const int nout = (a.epi == WN_EPI_GATE_BWD) ? 2 : 1;
+    wn_static_for<(JT + 1) / 2>([&](auto gc) {
+      constexpr int g2 = decltype(gc)::value;          // pair of row tiles -> 64 channels
+      for (int part = 0; part < nout; ++part) {
+        f32x16 outv[2];
+        wn_static_for<2>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          constexpr int j = 2 * g2 + jj;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int n0 = 32 * (jb + j) + 8 * rq + 4 * h;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (j < JT && n0 < a.N && tin) {
+              v[0] = acc[j < JT ? j : 0][4 * rq + 0] * inv_sc; v[1] = acc[j < JT ? j : 0][4 * rq + 1] * inv_sc;
+              v[2] = acc[j < JT ? j : 0][4 * rq + 2] * inv_sc; v[3] = acc[j < JT ? j : 0][4 * rq + 3] * inv_sc;
+              if (a.bias) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n0);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+              }
+              if (a.rowbias) {
+                const f32x4 rb = *reinterpret_cast<const f32x4*>(a.rowbias + (int64_t)b * a.ld_rowbias + n0);
+                v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
+              }
+              if (a.addc) {
+                const f32x4 cv = *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0);
+                v[0] += cv.x; v[1] += cv.y; v[2] += cv.z; v[3] += cv.w;
+              }
+              if (a.epi == WN_EPI_PLAIN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], a.act);
+              } else if (a.epi == WN_EPI_DACT) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                v[0] *= wn_dact_from_y(yv.x, a.act); v[1] *= wn_dact_from_y(yv.y, a.act);
+                v[2] *= wn_dact_from_y(yv.z, a.act); v[3] *= wn_dact_from_y(yv.w, a.act);
+              } else {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0);
+                if (part == 0) {
+                  v[0] *= gv.x * (1.f - av.x * av.x); v[1] *= gv.y * (1.f - av.y * av.y);
+                  v[2] *= gv.z * (1.f - av.z * av.z); v[3] *= gv.w * (1.f - av.w * av.w);
+                } else {
+                  v[0] *= av.x * gv.x * (1.f - gv.x); v[1] *= av.y * gv.y * (1.f - gv.y);
+                  v[2] *= av.z * gv.z * (1.f - gv.z); v[3] *= av.w * gv.w * (1.f - gv.w);
+                }
+              }
+              wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+            outv[jj][4 * rq + 0] = v[0]; outv[jj][4 * rq + 1] = v[1];
+            outv[jj][4 * rq + 2] = v[2]; outv[jj][4 * rq + 3] = v[3];
+          }
+        });
+        // stage (32 x 64) and store the valid part as row segments
+        const int c0 = 32 * (jb + 2 * g2);             // first channel of this group
+        if (c0 < a.N) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              f32x4 o;
+              o.x = outv[jj][4 * rq + 0]; o.y = outv[jj][4 * rq + 1]; o.z = outv[jj][4 * rq + 2]; o.w = outv[jj][4 * rq + 3];
+              *reinterpret_cast<f32x4*>(stage + tl * PITCH + 32 * jj + 8 * rq + 4 * h) = o;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int ncols = min(64, a.N - c0);         // multiple of 32
+          float* dst = a.y + row0 * a.ldy + (part ? a.N : 0) + c0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int r = i * 4 + (lane >> 4);
+            const int col = (lane & 15) * 4;
+            const f32x4 o = *reinterpret_cast<const f32x4*>(stage + r * PITCH + col);
+            if (r < rows_valid && col < ncols) *reinterpret_cast<f32x4*>(dst + (int64_t)r * a.ldy + col) = o;
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+    });
+  }
+}
+
 template <int JT>
 __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, const float* w16, int nks_total,
                                                                 const float* absmax_in0, const float* absmax_in1,
@@ -200,87 +291,143 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
       __syncthreads();
     }
 
-    // ---- epilogue in registers (D layout), then staged row stores, 64 channels at a time ----
-    if (!live) continue;
-    const int64_t row = row0 + tl;
-    const bool tin = t < a.T;
-    // GATE_BWD produces two outputs per accumulator; they are staged one after the other
-    const int nout = (a.epi == WN_EPI_GATE_BWD) ? 2 : 1;
-    wn_static_for<(JT + 1) / 2>([&](auto gc) {
-      constexpr int g2 = decltype(gc)::value;          // pair of row tiles -> 64 channels
-      for (int part = 0; part < nout; ++part) {
-        f32x16 outv[2];
-        wn_static_for<2>([&](auto jc) {
-          constexpr int jj = decltype(jc)::value;
-          constexpr int j = 2 * g2 + jj;
+    if (live) wn_g16_epilogue<JT, PITCH>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
+  }
+  if (absmax_out) {
 #pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const int n0 = 32 * (jb + j) + 8 * rq + 4 * h;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (j < JT && n0 < a.N && tin) {
-              v[0] = acc[j < JT ? j : 0][4 * rq + 0] * inv_sc; v[1] = acc[j < JT ? j : 0][4 * rq + 1] * inv_sc;
-              v[2] = acc[j < JT ? j : 0][4 * rq + 2] * inv_sc; v[3] = acc[j < JT ? j : 0][4 * rq + 3] * inv_sc;
-              if (a.bias) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n0);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-              }
-              if (a.rowbias) {
-                const f32x4 rb = *reinterpret_cast<const f32x4*>(a.rowbias + (int64_t)b * a.ld_rowbias + n0);
-                v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
-              }
-              if (a.addc) {
-                const f32x4 cv = *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0);
-                v[0] += cv.x; v[1] += cv.y; v[2] += cv.z; v[3] += cv.w;
-              }
-              if (a.epi == WN_EPI_PLAIN) {
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+  }
+}
+
+// Resident form for contractions whose whole hi|lo weight image fits LDS next to the stages
+// (<= 80 KiB: the per-block backward products d z and d x): weights are loaded once per
+// persistent workgroup and the tile loop has NO barrier, so the 8 waves drift apart and one wave's
+// epilogue / load latency hides under the others' MFMAs (same structure as wn_layer16.hip).
+template <int JT>
+struct WnG16R {
+  static constexpr int MAX_W_BYTES = 81920;
+  static constexpr int PITCH = 68;
+  static constexpr int STAGE_BYTES = 32 * PITCH * 4;
+  static constexpr int WAVES = 8;
+  static constexpr int LDS_BYTES = MAX_W_BYTES + WAVES * STAGE_BYTES;       // 151552
+  static constexpr int PF = 4;                                              // k-steps of activations in flight
+};
+
+template <int JT>
+__global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmArgs a, const float* w16, int nks_total,
+                                                                         const float* absmax_in0, const float* absmax_in1,
+                                                                         float* absmax_out) {
+  using G = WnG16R<JT>;
+  constexpr int PITCH = G::PITCH, PF = G::PF;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tl = lane & 31, h = lane >> 5;
+  float* stage = reinterpret_cast<float*>(smem + G::MAX_W_BYTES + wave * G::STAGE_BYTES);
+  {
+    const int n16 = nks_total * JT * 128;                // 16-byte pieces of the image (JTtot == JT)
+    const f32x4* src = reinterpret_cast<const f32x4*>(w16);
+    f32x4* dst = reinterpret_cast<f32x4*>(smem);
+    for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+  }
+  __syncthreads();
+  const h8* wl = reinterpret_cast<const h8*>(smem) + lane;
+
+  float sc = 1.0f, inv_sc = 1.0f;
+  if (absmax_in0) {
+    float m = *absmax_in0;
+    if (absmax_in1) m = fmaxf(m, *absmax_in1);
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);
+      e = max(-100, min(100, e));
+      sc = ldexpf(1.0f, -e);
+      inv_sc = ldexpf(1.0f, e);
+    }
+  }
+  int ks_end[WN_MAXSEG];
+  {
+    int acc = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], a.act);
-              } else if (a.epi == WN_EPI_DACT) {
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
-                v[0] *= wn_dact_from_y(yv.x, a.act); v[1] *= wn_dact_from_y(yv.y, a.act);
-                v[2] *= wn_dact_from_y(yv.z, a.act); v[3] *= wn_dact_from_y(yv.w, a.act);
-              } else {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0);
-                if (part == 0) {
-                  v[0] *= gv.x * (1.f - av.x * av.x); v[1] *= gv.y * (1.f - av.y * av.y);
-                  v[2] *= gv.z * (1.f - av.z * av.z); v[3] *= gv.w * (1.f - av.w * av.w);
-                } else {
-                  v[0] *= av.x * gv.x * (1.f - gv.x); v[1] *= av.y * gv.y * (1.f - gv.y);
-                  v[2] *= av.z * gv.z * (1.f - gv.z); v[3] *= av.w * gv.w * (1.f - gv.w);
-                }
-              }
-              wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            }
-            outv[jj][4 * rq + 0] = v[0]; outv[jj][4 * rq + 1] = v[1];
-            outv[jj][4 * rq + 2] = v[2]; outv[jj][4 * rq + 3] = v[3];
+    for (int s = 0; s < WN_MAXSEG; ++s) {
+      if (s < a.nseg) acc += (a.seg[s].K + 15) >> 4;
+      ks_end[s] = acc;
+    }
+  }
+  float wmax = 0.f;
+  const int tiles_per_b = (a.T + 31) >> 5;
+  const int64_t ntiles = (int64_t)a.B * tiles_per_b;
+  for (int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * G::WAVES) {
+    const int b = (int)(tile / tiles_per_b);
+    const int t0 = (int)(tile % tiles_per_b) * 32;
+    const int t = t0 + tl;
+    const int rows_valid = min(32, a.T - t0);
+    const int64_t row0 = (int64_t)b * a.T + t0;
+    const float* xrow_s[WN_MAXSEG];
+    bool xok_s[WN_MAXSEG];
+#pragma unroll
+    for (int s = 0; s < WN_MAXSEG; ++s) {
+      xrow_s[s] = nullptr;
+      xok_s[s] = false;
+      if (s < a.nseg) {
+        const int ts = t - a.seg[s].shift;
+        xok_s[s] = t < a.T && ts >= 0 && ts < a.T;
+        xrow_s[s] = a.seg[s].x + ((int64_t)b * a.T + (xok_s[s] ? ts : 0)) * a.seg[s].ldx + 4 * h;
+      }
+    }
+    auto load_x = [&](int ks, f32x4& q0, f32x4& q1) {
+      q0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      q1 = q0;
+      if (ks >= nks_total) return;
+      const float* xr = xrow_s[0];
+      bool ok = xok_s[0];
+      int kk = ks;
+#pragma unroll
+      for (int s = 1; s < WN_MAXSEG; ++s)
+        if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }
+      if (ok) {
+        q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
+        q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
+      }
+    };
+    f32x16 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // activations PF k-steps ahead in two named register sets
+    f32x4 xa[PF][2], xb[PF][2];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load_x(k, xa[k][0], xa[k][1]);
+    auto compute = [&](int ks0, const f32x4 (&xv)[PF][2]) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        if (ks0 + k < nks_total) {                       // wave-uniform
+          h8 bh, bl;
+          wn_split8g(xv[k][0], xv[k][1], sc, bh, bl);
+#pragma unroll
+          for (int j = 0; j < JT; ++j) {
+            const h8 ah = wl[(((ks0 + k) * JT + j) * 2 + 0) * 64];
+            const h8 al = wl[(((ks0 + k) * JT + j) * 2 + 1) * 64];
+            acc[j] = wn_mfma16g(al, bh, acc[j]);
+            acc[j] = wn_mfma16g(ah, bl, acc[j]);
+            acc[j] = wn_mfma16g(ah, bh, acc[j]);
           }
-        });
-        // stage (32 x 64) and store the valid part as row segments
-        const int c0 = 32 * (jb + 2 * g2);             // first channel of this group
-        if (c0 < a.N) {
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              f32x4 o;
-              o.x = outv[jj][4 * rq + 0]; o.y = outv[jj][4 * rq + 1]; o.z = outv[jj][4 * rq + 2]; o.w = outv[jj][4 * rq + 3];
-              *reinterpret_cast<f32x4*>(stage + tl * PITCH + 32 * jj + 8 * rq + 4 * h) = o;
-            }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const int ncols = min(64, a.N - c0);         // multiple of 32
-          float* dst = a.y + row0 * a.ldy + (part ? a.N : 0) + c0;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int r = i * 4 + (lane >> 4);
-            const int col = (lane & 15) * 4;
-            const f32x4 o = *reinterpret_cast<const f32x4*>(stage + r * PITCH + col);
-            if (r < rows_valid && col < ncols) *reinterpret_cast<f32x4*>(dst + (int64_t)r * a.ldy + col) = o;
-          }
-          asm volatile("" ::: "memory");
         }
       }
-    });
+    };
+    for (int ks0 = 0; ks0 < nks_total; ks0 += 2 * PF) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) load_x(ks0 + PF + k, xb[k][0], xb[k][1]);
+      compute(ks0, xa);
+      if (ks0 + PF >= nks_total) break;
+#pragma unroll
+      for (int k = 0; k < PF; ++k) load_x(ks0 + 2 * PF + k, xa[k][0], xa[k][1]);
+      compute(ks0 + PF, xb);
+    }
+    wn_g16_epilogue<JT, PITCH>(a, acc, inv_sc, 0, b, t, row0, rows_valid, stage, lane, wmax);
   }
   if (absmax_out) {
 #pragma unroll
@@ -308,7 +455,10 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   int64_t gx = (tiles + 7) / 8;
   if (gx > 256) gx = 256;
   const int jt_need = (a.N + 31) / 32;
-  if (jt_need <= 2) {
+  // knob 2 = 1 disables the resident form
+  if (jt_need == 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1) {
+    hipLaunchKernelGGL(wn_gemm_rows16_resident_kernel<2>, dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+  } else if (jt_need <= 2) {
     hipLaunchKernelGGL(wn_gemm_rows16_kernel<2>, dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   } else {
     // 128 output channels per workgroup column; wider outputs re-read the activations per column

@@ -79,6 +79,7 @@ int wn_launch_wgrad(const WnWgradArgs& a, hipStream_t s);
 // workspace base (operands) and to a slab row / the flat gradient buffer (outputs)
 struct WnWgJob {
   int64_t x_off, g_off, out_off, bias_off;   // bias_off < 0: no bias sum from this job
+  int64_t gmax_off;                          // workspace offset of the running max-abs of g, or < 0
   int32_t ldx, ldg, K, N, shift, k0, n0, pad_;
 };
 int wn_wgrad_tile_k();

@@ -1040,13 +1040,14 @@ int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float
 
 // ---- batched weight-gradient job table for one (B, T) layout ----
 void add_jobs(std::vector<WnWgJob>& jobs, int64_t x_off, int ldx, int K, int shift, int64_t g_off, int ldg, int N,
-              int64_t out_off, int64_t bias_off) {
+              int64_t out_off, int64_t bias_off, int64_t gmax_off) {
   const int tk = wn_wgrad_tile_k(), tn = wn_wgrad_tile_n();
   for (int k0 = 0; k0 < K; k0 += tk)
     for (int n0 = 0; n0 < N; n0 += tn) {
       WnWgJob j;
       memset(&j, 0, sizeof(j));
       j.x_off = x_off; j.g_off = g_off; j.out_off = out_off; j.bias_off = (k0 == 0) ? bias_off : -1;
+      j.gmax_off = gmax_off;
       j.ldx = ldx; j.ldg = ldg; j.K = K; j.N = N; j.shift = shift; j.k0 = k0; j.n0 = n0;
       jobs.push_back(j);
     }
@@ -1057,11 +1058,16 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   std::vector<WnWgJob> jobs;
   std::vector<WnTensorDesc> cov;
   auto cover = [&](int t) { WnTensorDesc d; d.off = p->tensors[t].off; d.len = p->tensors[t].len; cov.push_back(d); };
+  // running max-abs slots (same numbering as in wn_train_fwd_bwd): GF[i] | g_skipsum | GU[b] | GH[b]
+  const int nfin = (int)p->finals.size();
+  const int64_t am_skip = L.absmax + nfin;
+  auto am_GU = [&](int b) { return L.absmax + nfin + 1 + b; };
+  auto am_GH = [&](int b) { return L.absmax + nfin + 1 + p->N + b; };
   // input causal conv: x = inputs (B,T,1), g = d loss / d H[0]
   for (int t = 0; t < p->KS; ++t)
     add_jobs(jobs, L.probs, 1, 1, p->KS - 1 - t, L.GH[0], p->R, p->R,
              p->tensors[p->causal.kernel_t].off + (int64_t)t * p->R,
-             t == p->KS - 1 ? p->tensors[p->causal.bias_t].off : -1);
+             t == p->KS - 1 ? p->tensors[p->causal.bias_t].off : -1, am_GH(0));
   cover(p->causal.kernel_t); cover(p->causal.bias_t);
   for (int b = 0; b < p->N; ++b) {
     const BlockInfo& bi = p->blocks[b];
@@ -1069,15 +1075,16 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     for (int t = 0; t < p->KS; ++t)
       add_jobs(jobs, L.H[b], p->R, p->R, (p->KS - 1 - t) * c.dil, L.GU[b], 2 * p->D, 2 * p->D,
                p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D,
-               t == p->KS - 1 ? p->tensors[c.bias_t].off : -1);
+               t == p->KS - 1 ? p->tensors[c.bias_t].off : -1, am_GU(b));
     cover(c.kernel_t); cover(c.bias_t);
     const int64_t zoff = L.Z + (int64_t)b * p->Dp;
+    // S == 0: g_o = g_xout + g_skip (or a copy of g_skip): bounded by twice the larger max-abs -> no slot
     add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, p->S == 0 ? L.GO[b] : L.GH[b + 1], p->R, p->R,
-             p->tensors[bi.conv1.kernel_t].off, p->tensors[bi.conv1.bias_t].off);
+             p->tensors[bi.conv1.kernel_t].off, p->tensors[bi.conv1.bias_t].off, p->S == 0 ? am_skip : am_GH(b + 1));
     cover(bi.conv1.kernel_t); cover(bi.conv1.bias_t);
     if (bi.has_skip && p->c.use_skip) {
       add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, L.g_skipsum, p->S, p->S,
-               p->tensors[bi.conv_skip.kernel_t].off, p->tensors[bi.conv_skip.bias_t].off);
+               p->tensors[bi.conv_skip.kernel_t].off, p->tensors[bi.conv_skip.bias_t].off, am_skip);
       cover(bi.conv_skip.kernel_t); cover(bi.conv_skip.bias_t);
     }
   }
@@ -1085,7 +1092,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     const ConvInfo& c = p->finals[i];
     const int64_t xin = (i == 0) ? (p->c.use_skip ? L.skipsum : L.H[p->N]) : L.HA[i - 1];
     add_jobs(jobs, xin, c.cin, c.cin, 0, L.GF[i], c.cout, c.cout, p->tensors[c.kernel_t].off,
-             p->tensors[c.bias_t].off);
+             p->tensors[c.bias_t].off, L.absmax + (int64_t)i);
     cover(c.kernel_t); cover(c.bias_t);
   }
   if (p->d_jobs) { (void)hipFree(p->d_jobs); p->d_jobs = nullptr; }
