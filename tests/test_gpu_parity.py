@@ -21,6 +21,16 @@ def dev():
   return torch.device('cuda', 0)
 
 
+@pytest.fixture(params=['split', 'fp32'])
+def math_mode(request):
+  """Both contraction modes: 'split' = fp16 hi/lo 3-product MFMA (default), 'fp32' = exact-fp32 MFMA
+  (debug knob 1).  The tolerance is the same 1e-4 / bit-exact bar for both."""
+  from wavenets_amd import _lib
+  _lib.lib().wn_debug_set(1, 1 if request.param == 'fp32' else 0)
+  yield request.param
+  _lib.lib().wn_debug_set(1, 0)
+
+
 def _rel(a, b):
   a, b = a.double().cpu(), b.double().cpu()
   return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
@@ -113,7 +123,7 @@ LAYER_CASES = [
 
 
 @pytest.mark.parametrize('R,D,S,dil,k,act,residual,T', LAYER_CASES)
-def test_layer_forward_parity(R, D, S, dil, k, act, residual, T):
+def test_layer_forward_parity(R, D, S, dil, k, act, residual, T, math_mode):
   layer, ps, dl = _layer_pair(R, D, S, dil, k, act, residual)
   x = torch.randn(3, T, R, generator=torch.Generator().manual_seed(5)) * 0.7
   xo_ref, sk_ref = O.layer_forward(x.double(), [p.double() for p in ps], dilations=dl, activation_name=act,
@@ -233,7 +243,7 @@ def _inputs(kw, B, T, seed=3):
 
 
 @pytest.mark.parametrize('name', list(MODEL_CASES))
-def test_model_forward_parity(name):
+def test_model_forward_parity(name, math_mode):
   kw = dict(MODEL_CASES[name])
   ocfg, params, model = make_pair(seed=1, **kw)
   B, T = 3, 333
@@ -248,7 +258,7 @@ def test_model_forward_parity(name):
   assert (lg.cpu().double() - inter['logits']).abs().max() < ATOL_ACT
 
 
-def test_model_forward_cfg1_full_size():
+def test_model_forward_cfg1_full_size(math_mode):
   # BASELINE configs[0]: 10-layer mu-law-256, dilations 1..512, 32 residual ch, batch 1 x 16000
   kw = dict(blocks=10, channels=32, dilation_bound=1024, final_layers_channels=[], bits=8)
   ocfg, params, model = make_pair(seed=2, **kw)
@@ -266,7 +276,7 @@ def test_model_forward_cfg1_full_size():
 # training step: loss, gradients, optimizer
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('name', list(MODEL_CASES))
-def test_loss_and_gradients_parity(name):
+def test_loss_and_gradients_parity(name, math_mode):
   kw = dict(MODEL_CASES[name])
   ocfg, params, model = make_pair(seed=4, **kw)
   B, T = 2, 150
