@@ -46,6 +46,7 @@ struct BlockInfo {
   ConvInfo conv1, conv_skip, conv_cond;
   bool has_skip = false, has_cond = false;
   int64_t g16u = -1;    // fp16 split image [W_r | W_s] (backward: d z) or -1
+  int64_t g16r = -1;    // fp16 split image [W_r] alone (used with the precomputed W_s g_skip slice) or -1
 };
 
 }  // namespace
@@ -61,6 +62,7 @@ struct wn_plan {
   std::vector<ConvInfo> finals, mapping;
   int64_t frag_skipF = -1;     // A[Sh][N*Dp] image of the folded skip sum
   int64_t frag16_skipF = -1;   // the same as an fp16 split image, or -1
+  int64_t frag16_gzs = -1;     // fp16 split image A[N*D][S]: rows b*D.. = W_s of block b (backward of the folded skip sum)
   int64_t frag_floats = 0;
   std::vector<WnPrepDesc> prep;
   std::vector<WnTensorDesc> tdesc, kdesc;
@@ -163,11 +165,12 @@ int64_t new_image16(wn_plan* p, int I, int Ktotal) {
   p->frag_floats += (int64_t)wn_frag16_floats(I, Ktotal);
   return off;
 }
-void add_piece16(wn_plan* p, int64_t img, int I, int64_t src_off, int KK, int ld, int transpose, int ks_off) {
+void add_piece16(wn_plan* p, int64_t img, int I, int64_t src_off, int KK, int ld, int transpose, int ks_off,
+                 int j_off = 0, int JT_img = 0) {
   WnPrepDesc d;
   memset(&d, 0, sizeof(d));
   d.src_off = src_off; d.dst_off = img; d.I = I; d.KK = KK; d.ld = ld; d.transpose = transpose;
-  d.q_off = ks_off; d.j_off = 0; d.JT = ceil32(I); d.kind = 1;
+  d.q_off = ks_off; d.j_off = j_off; d.JT = JT_img > 0 ? JT_img : ceil32(I); d.kind = 1;
   p->prep.push_back(d);
 }
 inline bool m16(int v) { return v > 0 && v % 16 == 0; }
@@ -214,6 +217,7 @@ struct WsLayout {
   int64_t slab, slab_floats;
   std::vector<int64_t> GU, GH, GO, GF;  // deferred-wgrad mode: per-block g_u, g_h (N+1), g_o; per-final g
   int64_t bslab; int bsplits;           // batched slab [B*bsplits][nparams]
+  int64_t GZS;                          // [rows][N*D] precomputed W_s g_skip of every block, or 0
   int64_t absmax; int n_absmax;         // running max-abs scalars: GF[i] | g_skipsum | GU[b] | GH[b]
   int64_t sum_scratch;
   std::vector<int64_t> M;               // mapping activations [B][w]
@@ -278,6 +282,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
   L.loss_rows = cv.take(rows);
   L.yt = cv.take(rows);
   L.sum_scratch = cv.take(2048 + 64);
+  L.GZS = 0;
   L.n_absmax = (int)p->finals.size() + 1 + p->N + (p->N + 1);
   L.absmax = cv.take(L.n_absmax);
   // conditioning
@@ -318,6 +323,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
       for (int b = 0; b <= p->N; ++b) L.GH.push_back(cv.take(rows * p->R));
       if (p->S == 0) for (int b = 0; b < p->N; ++b) L.GO.push_back(cv.take(rows * p->R));
       for (size_t i = 0; i < p->finals.size(); ++i) L.GF.push_back(cv.take(rows * p->finals[i].cout));
+      L.GZS = p->frag16_gzs >= 0 ? cv.take(rows * p->N * p->D) : 0;
       const int nj = count_jobs(p);
       int sp = (int)((5000 + (int64_t)nj * B - 1) / ((int64_t)nj * B));
       const int maxsp = std::max(1, (T + 255) / 256);
@@ -435,6 +441,7 @@ struct BlockPtrs {
   bool fused;
   const float* F16d; const float* F16r;   // fp16 split images of the gated conv / conv1, or null
   const float* G16u; const float* G16x;   // fp16 split images of the backward-data products, or null
+  const float* G16r;                      // [W_r] alone
 };
 
 struct BlockBufs {
@@ -518,6 +525,7 @@ struct BlockGrads {
   bool defer;               // weight gradients are computed later by the batched job table
   const float* am_gxout; const float* am_gskip;   // running max-abs of g_xout / g_skip (or null)
   float* am_gu; float* am_gx;                      // where to publish max-abs of g_u / g_x (or null)
+  const float* gzs; int ld_gzs;                    // precomputed W_s g_skip slice of this block, or null
 };
 
 int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, hipStream_t s) {
@@ -540,9 +548,13 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
   // g_u = gate'( W_r g_o + W_s g_skip )
   {
     Gemm gm(k.B, k.T, k.D, ceil32(k.D));
+    const bool use_gzs = g.gzs && g_o && k.G16r && g.am_gu && g.am_gxout && k.Cc == 0;
     if (g_o) gm.seg(g_o, k.R, k.R, 0, k.Br_);
-    if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, k.Bs);
-    if (gm.a.nseg == 0) {
+    if (use_gzs) gm.addc(g.gzs, g.ld_gzs).w16(k.G16r).absmax(g.am_gxout, nullptr, g.am_gu);
+    else if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, k.Bs);
+    if (use_gzs) {
+      rc = gm.gate_bwd(f.AG, 2 * k.D).run(g.g_u, 2 * k.D, s);
+    } else if (gm.a.nseg == 0) {
       rc = wn_launch_fill(g.g_u, 0.f, rows * 2 * k.D, s);
     } else {
       // the [W_r | W_s] image matches the segment list only when both (or, for S == 0, the single) operands exist
@@ -757,6 +769,17 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
       if (bi.has_skip) add_piece16(p, bi.g16u, p->D, p->tensors[bi.conv_skip.kernel_t].off, p->S, p->S, 0, p->R / 16);
     }
   }
+  if (p->LPB == 1 && p->c.use_skip && p->S > 0 && m32(p->D) && m16(p->S) && m16(p->R) && p->Dp == p->D) {
+    // W_s g_skip for ALL blocks in one contraction (g_skip is shared): image rows b*D.. = W_s of block b
+    p->frag16_gzs = new_image16(p, p->N * p->D, p->S);
+    for (int b = 0; b < p->N; ++b) {
+      BlockInfo& bi = p->blocks[b];
+      add_piece16(p, p->frag16_gzs, p->D, p->tensors[bi.conv_skip.kernel_t].off, p->S, p->S, 0, 0, b * (p->D / 32),
+                  p->N * p->D / 32);
+      bi.g16r = new_image16(p, p->D, p->R);
+      add_piece16(p, bi.g16r, p->D, p->tensors[bi.conv1.kernel_t].off, p->R, p->R, 0, 0);
+    }
+  }
   if (p->LPB == 1 && m32(p->R) && m16(2 * p->D)) {
     for (BlockInfo& bi : p->blocks) {
       // d x = sum_tap W_tap g_u[t + shift] : image of KS pieces A[R][2D], I = R
@@ -864,6 +887,7 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   k.fused = p->fused_ok;
   if (p->fused16_ok && p->LPB == 1) { k.F16d = fragbase + bi.dil.back().frag16; k.F16r = fragbase + bi.conv1.frag16; }
   if (bi.g16u >= 0) k.G16u = fragbase + bi.g16u;
+  if (bi.g16r >= 0) k.G16r = fragbase + bi.g16r;
   if (p->LPB == 1 && bi.dil[0].frag16B >= 0) k.G16x = fragbase + bi.dil[0].frag16B;
   return k;
 }
@@ -1225,6 +1249,21 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       rc = wn_launch_fill(ws + L.GH[p->N], 0.f, rows * p->R, s);   // nothing flows into the last block output
       if (rc) return rc;
     }
+    // W_s g_skip of every block in ONE contraction: each block then reads its D-column slice (33 MB at
+    // configs[1]) instead of re-reading g_skip (131 MB).  Measured SLOWER on configs[1] (12.6 vs 12.0 ms
+    // per step: the 1920-column product and the strided slice reads cost more than the re-reads save),
+    // so it is opt-in (knob 4 = 1).
+    bool have_gzs = false;
+    if (L.GZS > 0 && p->frag16_gzs >= 0 && wn_debug_get(1) != 1 && wn_debug_get(4) == 1) {
+      Gemm gz(B, T, p->N * p->D, p->N * p->D / 32);
+      gz.seg(g_skip, p->S, p->S, 0, nullptr).w16(fragbase + p->frag16_gzs).absmax(am_gskip, nullptr, nullptr);
+      gz.a.y = ws + L.GZS; gz.a.ldy = p->N * p->D; gz.a.vec_out = 1;
+      if (wn_gemm_rows16_ok(gz.a)) {
+        rc = gz.run(ws + L.GZS, p->N * p->D, s);
+        if (rc) return rc;
+        have_gzs = true;
+      }
+    }
     for (int b = p->N - 1; b >= 0; --b) {
       BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
       const BlockInfo& bi = p->blocks[b];
@@ -1247,6 +1286,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       bg.am_gxout = bg.g_xout ? am_GH(b + 1) : nullptr;
       bg.am_gskip = g_skip ? am_gskip : nullptr;
       bg.am_gu = am_GU(b); bg.am_gx = am_GH(b);
+      if (have_gzs) { bg.gzs = ws + L.GZS + (int64_t)b * p->D; bg.ld_gzs = p->N * p->D; }
       rc = block_backward(k, f, bg, s);
       if (rc) return rc;
       if (p->S == 0 && bg.g_xout == nullptr && g_skip) {
