@@ -89,6 +89,12 @@ int32_t wn_plan_dilation(const wn_plan* p, int32_t conv_index);   /* src/model.p
 /* workspace size in floats for a (B, T) call; training != 0 keeps activations for backward */
 int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t T, int32_t training);
 
+/* ---- Dropout(rate) on every block input in training calls (src/layers.py:108-111,195-196; WaveNet
+ * keyword `dropout`).  The keep-mask is a counter-based hash of (seed, block, step, element); `step`
+ * is the value BEFORE the next wn_train_fwd_bwd (each call pre-increments it).  rate 0 disables. */
+int wn_plan_set_dropout(wn_plan* p, float rate, uint64_t seed, uint64_t step);
+uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* test hook */
+
 /* ---- measurement hook (bench.py): HIP events around each residual-block forward launch on
  * the caller's stream; wn_prof_read returns the average per-launch time after a stream sync.
  * Not part of the reference surface. */

@@ -217,9 +217,39 @@ class _ParamCursor:
     return out
 
 
+def _hash32(x: np.ndarray) -> np.ndarray:
+  x = x.astype(np.uint64)
+  m = np.uint64(0xFFFFFFFF)
+  x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m
+  x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m
+  x ^= x >> np.uint64(16)
+  return x
+
+
+def dropout_key(seed: int, block: int, step: int) -> int:
+  """Restates wn_dropout_key (wavenets_amd/csrc/wn_elem.hip); all arithmetic mod 2^32."""
+  M = 0xFFFFFFFF
+  k = ((seed & M) * 0x9E3779B9 + (seed >> 32)) & M
+  k ^= ((block & M) * 0x85EBCA6B + 0x1234567) & M
+  k ^= (((step & M) * 0xC2B2AE35) + ((step >> 32) & M) * 0x27D4EB2F) & M
+  return k
+
+
+def dropout_keep_mask(n: int, key: int, rate: float) -> torch.Tensor:
+  """Keep-mask of the product's stateless dropout hash over element indices 0..n-1 (the TF
+  random stream of tf.keras.layers.Dropout, src/layers.py:108-111, is not reproducible)."""
+  idx = np.arange(n, dtype=np.uint64)
+  lo = idx & np.uint64(0xFFFFFFFF)
+  hi = idx >> np.uint64(32)
+  h = _hash32(lo ^ _hash32((hi + np.uint64(key)) & np.uint64(0xFFFFFFFF)))
+  u = (h >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+  return torch.from_numpy(u >= np.float32(rate))
+
+
 def layer_forward(x: torch.Tensor, layer_params: Sequence[torch.Tensor], *,
                   dilations: Sequence[int], activation_name: Optional[str],
-                  residual: bool, has_skip: bool, cond: Optional[torch.Tensor] = None
+                  residual: bool, has_skip: bool, cond: Optional[torch.Tensor] = None,
+                  drop: Optional[Tuple[float, int]] = None
                   ) -> Tuple[torch.Tensor, torch.Tensor]:
   """WaveNetLayer.call, src/layers.py:178-224 (dropout omitted: rate 0 in parity runs).
 
@@ -229,6 +259,10 @@ def layer_forward(x: torch.Tensor, layer_params: Sequence[torch.Tensor], *,
   cur = _ParamCursor(list(layer_params))
   res = x
   h = x
+  if drop is not None:                             # src/layers.py:192-196: conv input only
+    rate, key = drop
+    keep = dropout_keep_mask(x.numel(), key, rate).view(x.shape).to(x.dtype)
+    h = x * keep * (1.0 / (1.0 - np.float32(rate)).astype(np.float32).item())
   n = len(dilations)
   for i, d in enumerate(dilations):
     kern, b = cur.take(2)
@@ -274,7 +308,7 @@ def mapping_forward(cond: torch.Tensor, params: Sequence[torch.Tensor],
 
 def model_forward(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleConfig,
                   cond: Optional[torch.Tensor] = None, return_logits: bool = False,
-                  return_intermediates: bool = False):
+                  return_intermediates: bool = False, dropout: Optional[Tuple[float, int, int]] = None):
   """WaveNet.call, src/model.py:213-239.  x: (B,T,1); cond: (B, cond_inputs) or None.
 
   Returns probabilities for the categorical head (softmax activation on the last conv,
@@ -296,9 +330,12 @@ def model_forward(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleCo
   lpb = cfg.layers_per_block
   for b in range(cfg.blocks):
     lp = cur.take(npb)
+    drop = None
+    if dropout is not None and dropout[0] > 0:          # (rate, seed, step): training-mode dropout
+      drop = (dropout[0], dropout_key(dropout[1], b, dropout[2]))
     h, sk = layer_forward(h, lp, dilations=dil[b * lpb:(b + 1) * lpb],
                           activation_name=cfg.activation, residual=cfg.use_residual,
-                          has_skip=cfg.skip_channels is not None, cond=c)
+                          has_skip=cfg.skip_channels is not None, cond=c, drop=drop)
     skips.append(sk)
     inter['h'].append(h)
   if cfg.use_skip:
@@ -449,7 +486,7 @@ def l2_penalty(params: Sequence[torch.Tensor], cfg: OracleConfig) -> torch.Tenso
 
 def loss_and_grads(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleConfig,
                    cond: Optional[torch.Tensor] = None, global_batch: Optional[int] = None,
-                   n_replicas: int = 1):
+                   n_replicas: int = 1, dropout: Optional[Tuple[float, int, int]] = None):
   """Forward + loss + reverse-mode gradients of one replica's share of a train step.
 
   x: (B, T+1, 1).  inputs = x[:, :-1], target = prepare_target(x[:, 1:]) (src/model.py:
@@ -460,7 +497,7 @@ def loss_and_grads(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleC
   ps = [p.detach().clone().requires_grad_(True) for p in params]
   inputs, y_true = x[:, :-1, :], x[:, 1:, :]
   target = prepare_target(y_true, cfg)
-  pred = model_forward(inputs, ps, cfg, cond)
+  pred = model_forward(inputs, ps, cfg, cond, dropout=dropout)
   per = loss_fn(target, pred, cfg)                  # (B,T)
   Bg = x.shape[0] if global_batch is None else global_batch
   loss = per.sum() / Bg

@@ -480,3 +480,51 @@ def test_queued_generation_needs_depth_one():
   ocfg, params, model = make_pair(seed=7, **kw)
   with pytest.raises(NotImplementedError):
     model.generate(3, batch_size=1, use_queues=True, deterministic=True)
+
+
+# ------------------------------------------------------------------------------------------
+# dropout (reference default config: dropout 0.1, train.py:39) -- stateless hash mask restated by the oracle
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['cat_small_fused', 'cat_lpb3', 'cat_odd_composed', 'cat_noskipch'])
+def test_dropout_training_step_parity(name, math_mode):
+  from wavenets_amd import WaveNet, _lib
+  kw = dict(MODEL_CASES[name])
+  rate, seed = 0.25, 77
+  ocfg = O.OracleConfig(**kw)
+  params = O.init_params(ocfg, seed=4)
+  model = WaveNet(**kw, dropout=rate, device=dev(), seed=seed)
+  model.set_weights([p.numpy() for p in params])
+  B, T = 2, 140
+  x, _ = _inputs(kw, B, T + 1, seed=8)
+  for step in (1, 2):                     # the library pre-increments its step counter per call
+    loss_ref, _, grads_ref, _ = O.loss_and_grads(x.double(), [p.double() for p in params], ocfg,
+                                                 dropout=(rate, seed, step))
+    loss, _, _ = model.loss_and_grads(x.to(dev()))
+    assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item()))
+    for n, g, r in zip(model.variable_names, model.gradients(), grads_ref):
+      scale = max(r.abs().max().item(), 1e-6)
+      assert (g.cpu().double() - r).abs().max().item() < 1e-4 * scale + 1e-7, (n, step)
+  # masks differ between steps and the keep rate is right
+  k1 = O.dropout_keep_mask(200000, O.dropout_key(seed, 0, 1), rate)
+  k2 = O.dropout_keep_mask(200000, O.dropout_key(seed, 0, 2), rate)
+  assert not torch.equal(k1, k2)
+  assert abs(k1.float().mean().item() - (1 - rate)) < 5e-3
+  assert _lib.lib().wn_dropout_key_for(seed, 3, 9) == O.dropout_key(seed, 3, 9)
+  # inference ignores dropout
+  ref = O.model_forward(x[:, :-1].double(), [p.double() for p in params], ocfg)
+  assert (model(x[:, :-1].to(dev())).cpu().double() - ref).abs().max() < ATOL_ACT
+
+
+def test_layer_dropout_training_mode():
+  from wavenets_amd import WaveNetLayer
+  layer = WaveNetLayer(channels=32, skip_channels=32, dilation_rate=2, dropout=0.5, device=dev())
+  x = torch.randn(2, 64, 32, device=dev())
+  torch.manual_seed(0)
+  xo, sk = layer(x, training=True)
+  xe, se = layer(x, training=False)
+  assert xo.shape == xe.shape and not torch.allclose(xo, xe)
+  # the residual is not dropped: with zero conv weights the block is the identity in both modes
+  with torch.no_grad():
+    layer.flat_params.zero_()
+  xo, _ = layer(x, training=True)
+  assert torch.allclose(xo, x, atol=1e-6)

@@ -68,6 +68,8 @@ _SIGS = {
     'wn_plan_dilation': (C.c_int32, [_P, C.c_int32]),
     'wn_plan_workspace_floats': (C.c_int64, [_P, C.c_int32, C.c_int32, C.c_int32]),
     'wn_debug_set': (C.c_int, [C.c_int, C.c_int]),
+    'wn_plan_set_dropout': (C.c_int, [_P, C.c_float, C.c_uint64, C.c_uint64]),
+    'wn_dropout_key_for': (C.c_uint32, [C.c_uint64, C.c_int32, C.c_uint64]),
     'wn_prof_enable': (C.c_int, [_P, C.c_int32]),
     'wn_prof_read': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     'wn_forward': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),

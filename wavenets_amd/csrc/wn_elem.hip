@@ -621,3 +621,47 @@ int wn_launch_dact_mul(const float* g, const float* y, float* out, int64_t n, in
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Dropout on the block input (src/layers.py:108-111,195-196): keep-mask from a counter-based integer
+// hash of (seed, block, step, element index) -- reproducible, stateless, identical in forward and
+// backward (TF's own random stream is not reproducible; the CPU oracle restates this hash).
+//   forward : xd = keep ? x / (1 - rate) : 0
+//   backward: g_x = (keep ? g_xd / (1 - rate) : 0) + g_res      (g_res = residual path, may be null)
+__device__ __forceinline__ uint32_t wn_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool wn_drop_keep(int64_t idx, uint32_t key, float rate) {
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)((uint64_t)idx >> 32);
+  const uint32_t hsh = wn_hash32(lo ^ wn_hash32(hi + key));
+  return (float)(hsh >> 8) * (1.0f / 16777216.0f) >= rate;
+}
+__global__ void wn_dropout_kernel(const float* x, const float* g_res, float* out, int64_t n, float rate, float scale,
+                                  uint32_t key, float* absmax_out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = wn_drop_keep(i, key, rate) ? x[i] * scale : 0.f;
+    if (g_res) v += g_res[i];
+    out[i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  if (absmax_out) {
+    m = wn_wave_max(m);
+    if ((threadIdx.x & 63) == 0) wn_absmax_publish(absmax_out, m);
+  }
+}
+uint32_t wn_dropout_key(uint64_t seed, int block, uint64_t step) {
+  uint32_t k = (uint32_t)seed * 0x9E3779B9U + (uint32_t)(seed >> 32);
+  k ^= (uint32_t)block * 0x85EBCA6BU + 0x1234567U;
+  k ^= (uint32_t)step * 0xC2B2AE35U + (uint32_t)(step >> 32) * 0x27D4EB2FU;
+  return k;
+}
+int wn_launch_dropout(const float* x, const float* g_res, float* out, int64_t n, float rate, uint32_t key,
+                      float* absmax_out, hipStream_t s) {
+  if (n <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_dropout_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, x, g_res, out, n, rate, 1.0f / (1.0f - rate),
+                     key, absmax_out);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

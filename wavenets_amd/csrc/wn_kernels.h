@@ -123,6 +123,9 @@ int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s);
 int wn_launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
 int wn_launch_fill(float* p, float v, int64_t n, hipStream_t s);
 int wn_launch_dact_mul(const float* g, const float* y, float* out, int64_t n, int act, hipStream_t s);
+uint32_t wn_dropout_key(uint64_t seed, int block, uint64_t step);
+int wn_launch_dropout(const float* x, const float* g_res, float* out, int64_t n, float rate, uint32_t key,
+                      float* absmax_out, hipStream_t s);
 int wn_launch_gate(const float* u, int64_t rows, int D, float* ag, float* z, int ldz, hipStream_t s);
 int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s);
 int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, hipStream_t s);

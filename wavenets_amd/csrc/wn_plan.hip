@@ -71,10 +71,13 @@ struct wn_plan {
   WnTensorDesc* d_tdesc = nullptr;
   WnTensorDesc* d_kdesc = nullptr;
   bool fused_ok = false, fused16_ok = false;
+  float drop_rate = 0.f;        // Dropout rate applied to every block input in training (src/layers.py:108-111)
+  uint64_t drop_seed = 0, drop_step = 0;
   // batched weight-gradient job table (device), valid for one (B, T) workspace layout
   WnWgJob* d_jobs = nullptr;
   WnTensorDesc* d_cov = nullptr;
   int njobs = 0, ncov = 0, jobs_B = 0, jobs_T = 0, jobs_splits = 0;
+  bool jobs_drop = false;
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   int prof_used = 0;
@@ -218,6 +221,8 @@ struct WsLayout {
   std::vector<int64_t> GU, GH, GO, GF;  // deferred-wgrad mode: per-block g_u, g_h (N+1), g_o; per-final g
   int64_t bslab; int bsplits;           // batched slab [B*bsplits][nparams]
   int64_t GZS;                          // [rows][N*D] precomputed W_s g_skip of every block, or 0
+  std::vector<int64_t> XD;              // dropout: dropped copy of every block input (training)
+  int64_t gxd;                          // dropout: scratch for d loss / d (dropped input)
   int64_t absmax; int n_absmax;         // running max-abs scalars: GF[i] | g_skipsum | GU[b] | GH[b]
   int64_t sum_scratch;
   std::vector<int64_t> M;               // mapping activations [B][w]
@@ -296,6 +301,11 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     L.g_m1 = cv.take((int64_t)B * mw);
   } else {
     L.cb = L.dcb = L.g_m0 = L.g_m1 = 0;
+  }
+  L.gxd = 0;
+  if (training && p->drop_rate > 0.f) {
+    for (int b = 0; b < p->N; ++b) L.XD.push_back(cv.take(rows * p->R));
+    L.gxd = cv.take(rows * p->R);
   }
   if (training) {
     L.g_a = cv.take(rows * maxC);
@@ -453,6 +463,7 @@ struct BlockBufs {
   float* O;                 // [rows][R] pre-residual output or null
   float* x_out;             // [rows][R]
   const float* xt[3];       // queued generation: per-tap input rows (no time shift), or null
+  const float* res;         // residual source when it is not x (dropout: x is the dropped copy), or null
 };
 
 int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
@@ -476,7 +487,7 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     a.x = h; a.frag_d = use16 ? k.F16d : k.Fd[li]; a.frag_r = use16 ? k.F16r : k.Fr;
     a.bias_d = k.bd[li]; a.bias_r = k.br; a.cb = k.cb;
     a.x_out = f.x_out; a.o_out = f.O; a.z_out = f.Z; a.ldz = f.ldz; a.ag_out = f.AG;
-    a.res = (k.depth > 1) ? f.x : nullptr;
+    a.res = f.res ? f.res : ((k.depth > 1) ? f.x : nullptr);
     a.xt[0] = f.xt[0]; a.xt[1] = f.xt[1]; a.xt[2] = f.xt[2];
     a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
     return use16 ? wn_launch_layer_fwd_f16(a, s) : wn_launch_layer_fwd(a, s);
@@ -502,10 +513,10 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     if (f.O) {
       rc = g.run(f.O, k.R, s);
       if (rc) return rc;
-      if (k.residual) return wn_launch_add(f.O, f.x, f.x_out, rows * k.R, s);
+      if (k.residual) return wn_launch_add(f.O, f.res ? f.res : f.x, f.x_out, rows * k.R, s);
       return hipMemcpyAsync(f.x_out, f.O, rows * k.R * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
     }
-    if (k.residual) g.addc(f.x, k.Cin);
+    if (k.residual) g.addc(f.res ? f.res : f.x, k.Cin);
     return g.run(f.x_out, k.R, s);
   }
 }
@@ -526,6 +537,7 @@ struct BlockGrads {
   const float* am_gxout; const float* am_gskip;   // running max-abs of g_xout / g_skip (or null)
   float* am_gu; float* am_gx;                      // where to publish max-abs of g_u / g_x (or null)
   const float* gzs; int ld_gzs;                    // precomputed W_s g_skip slice of this block, or null
+  float drop_rate; uint32_t drop_key; float* g_xd;  // dropout on the block input: mask the conv-path gradient
 };
 
 int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, hipStream_t s) {
@@ -625,6 +637,16 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
       if (rc) return rc;
       gcur = dst; gc = k.D;
     } else {
+      if (g.drop_rate > 0.f) {
+        // conv-path gradient first, then the keep-mask, then the (unmasked) residual path
+        if (k.G16x && k.depth == 1 && g.am_gu) gm.w16(k.G16x).absmax(g.am_gu, nullptr, nullptr);
+        rc = gm.run(g.g_xd, hc, s);
+        if (rc) return rc;
+        rc = wn_launch_dropout(g.g_xd, (k.residual && g.g_xout) ? g.g_xout : nullptr, g.g_x, rows * hc, g.drop_rate,
+                               g.drop_key, g.am_gx, s);
+        if (rc) return rc;
+        continue;
+      }
       if (k.residual && g.g_xout) gm.addc(g.g_xout, k.R);
       if (k.G16x && k.depth == 1 && g.am_gu && g.am_gx) gm.w16(k.G16x).absmax(g.am_gu, nullptr, g.am_gx);
       rc = gm.run(g.g_x, hc, s);
@@ -803,6 +825,14 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_cov) (void)hipFree(p->d_cov);
   delete p;
 }
+
+// ---- Dropout(rate) on every block input in training mode (src/layers.py:108-111, 195-196) ----
+extern "C" int wn_plan_set_dropout(wn_plan* p, float rate, uint64_t seed, uint64_t step) {
+  if (!p || rate < 0.f || rate >= 1.f) { wn_set_error("Dropout must be between 0 and 1."); return WN_E_INVALID; }
+  p->drop_rate = rate; p->drop_seed = seed; p->drop_step = step;
+  return WN_OK;
+}
+extern "C" uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step) { return wn_dropout_key(seed, block, step); }
 
 // ---- profiling hook: HIP events around every residual-block forward launch ----
 extern "C" int wn_prof_enable(wn_plan* p, int32_t max_launches) {
@@ -991,6 +1021,14 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     memset(&f, 0, sizeof(f));
     const int hi = training ? b : (b & 1), ho = training ? b + 1 : ((b + 1) & 1);
     f.x = ws + L.H[hi];
+    if (training && p->drop_rate > 0.f) {
+      // x = dropout(x) feeds the dilated stack; the residual keeps the original (src/layers.py:192-196)
+      rc = wn_launch_dropout(ws + L.H[hi], nullptr, ws + L.XD[b], rows * p->R, p->drop_rate,
+                             wn_dropout_key(p->drop_seed, b, p->drop_step), nullptr, s);
+      if (rc) return rc;
+      f.x = ws + L.XD[b];
+      f.res = ws + L.H[hi];
+    }
     for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
     f.U = ws + L.U;
     f.AG = training ? ws + L.AG[b] : nullptr;
@@ -1078,7 +1116,8 @@ void add_jobs(std::vector<WnWgJob>& jobs, int64_t x_off, int ldx, int K, int shi
 }
 
 int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
-  if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits) return WN_OK;
+  if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
+      p->jobs_drop == (p->drop_rate > 0.f)) return WN_OK;
   std::vector<WnWgJob> jobs;
   std::vector<WnTensorDesc> cov;
   auto cover = [&](int t) { WnTensorDesc d; d.off = p->tensors[t].off; d.len = p->tensors[t].len; cov.push_back(d); };
@@ -1097,7 +1136,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     const BlockInfo& bi = p->blocks[b];
     const ConvInfo& c = bi.dil[0];
     for (int t = 0; t < p->KS; ++t)
-      add_jobs(jobs, L.H[b], p->R, p->R, (p->KS - 1 - t) * c.dil, L.GU[b], 2 * p->D, 2 * p->D,
+      add_jobs(jobs, p->drop_rate > 0.f ? L.XD[b] : L.H[b], p->R, p->R, (p->KS - 1 - t) * c.dil, L.GU[b], 2 * p->D, 2 * p->D,
                p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D,
                t == p->KS - 1 ? p->tensors[c.bias_t].off : -1, am_GU(b));
     cover(c.kernel_t); cover(c.bias_t);
@@ -1126,7 +1165,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   WN_HIP_CHECK(hipMalloc((void**)&p->d_cov, cov.size() * sizeof(WnTensorDesc)));
   WN_HIP_CHECK(hipMemcpy(p->d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
-  p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits;
+  p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
   return WN_OK;
 }
 
@@ -1183,6 +1222,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   if (ws_floats < L.total) { wn_set_error("train_fwd_bwd: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)L.total); return WN_E_INVALID; }
   if (global_batch <= 0) global_batch = B;
   if (n_replicas <= 0) n_replicas = 1;
+  p->drop_step += 1;                                   // a fresh dropout mask per training step
   float* ws = workspace;
   const int64_t rows = (int64_t)B * T;
   float* inputs = ws + L.probs;
@@ -1269,12 +1309,15 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       const BlockInfo& bi = p->blocks[b];
       BlockBufs f;
       memset(&f, 0, sizeof(f));
-      f.x = ws + L.H[b];
+      f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
       f.AG = ws + L.AG[b];
       f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
       BlockGrads bg;
       memset(&bg, 0, sizeof(bg));
       bg.defer = true;
+      if (p->drop_rate > 0.f) {
+        bg.drop_rate = p->drop_rate; bg.drop_key = wn_dropout_key(p->drop_seed, b, p->drop_step); bg.g_xd = ws + L.gxd;
+      }
       // the last block's output gradient is identically zero when the head reads the skip sum
       bg.g_xout = (p->c.use_skip && b == p->N - 1) ? nullptr : ws + L.GH[b + 1];
       bg.g_skip = g_skip;
@@ -1337,12 +1380,15 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     const BlockInfo& bi = p->blocks[b];
     BlockBufs f;
     memset(&f, 0, sizeof(f));
-    f.x = ws + L.H[b];
+    f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
     for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
     f.AG = ws + L.AG[b];
     f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
     BlockGrads bg;
     memset(&bg, 0, sizeof(bg));
+    if (p->drop_rate > 0.f) {
+      bg.drop_rate = p->drop_rate; bg.drop_key = wn_dropout_key(p->drop_seed, b, p->drop_step); bg.g_xd = ws + L.gxd;
+    }
     bg.g_xout = g_xout; bg.g_skip = g_skip; bg.g_o_tmp = ws + L.g_o; bg.g_u = ws + L.U; bg.g_p = ws + L.g_p;
     bg.g_x = ghbuf[b & 1];
     for (int i = 0; i < p->LPB; ++i) {

@@ -231,9 +231,15 @@ class WaveNetLayer(torch.nn.Module):
       self.build([tuple(x.shape), tuple(cond.shape)] if self.condition else tuple(x.shape))
     if self.condition and cond.shape[1] != x.shape[1]:
       raise ValueError('Condition tensor must have the same length as input')
-    if training and self.dropout is not None:
-      raise NotImplementedError('dropout > 0 in training mode is not built yet')
     flat = self.flat_params if self._owner is None else self._flat()
+    if training and self.dropout is not None:
+      # Dropout on the conv input only, not on the residual (src/layers.py:192-196):
+      # block(x) = convpath(dropout(x)) + x  =  fn(x_d) - x_d + x
+      x_d = self.dropout(x)
+      x_out, skip = _LayerFn.apply(self, x_d, cond, flat)
+      if self.residual:
+        x_out = x_out - x_d + x
+      return x_out, skip
     return _LayerFn.apply(self, x, cond, flat)
 
   def forward(self, inputs, training=False):

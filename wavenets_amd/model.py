@@ -179,6 +179,10 @@ class WaveNet(torch.nn.Module):
     if not plan:
       raise ValueError(L.wn_last_error_string().decode())
     self._plan = C.c_void_p(plan)
+    if s.dropout > 0:
+      if s.dropout >= 1:
+        raise ValueError('Dropout must be between 0 and 1.')
+      _lib.check(L.wn_plan_set_dropout(self._plan, s.dropout, self._seed, 0))
     shapes = s.param_shapes(cond_inputs)
     n = L.wn_plan_num_tensors(self._plan)
     assert n == len(shapes), (n, len(shapes))
@@ -301,7 +305,8 @@ class WaveNet(torch.nn.Module):
   def call(self, inputs, training=False):
     """src/model.py:213-239: probabilities (categorical) or linear mixture parameters."""
     if training and self.dropout > 0:
-      raise NotImplementedError('dropout > 0 in training mode is not built yet')
+      # dropout is applied inside train_step / loss_and_grads; a stand-alone stochastic forward is not exposed
+      raise NotImplementedError('call(training=True) with dropout > 0: use train_step / loss_and_grads')
     x, cond = self._split_inputs(inputs)
     B, T = x.shape[0], x.shape[1]
     L = _lib.lib()
@@ -338,8 +343,6 @@ class WaveNet(torch.nn.Module):
 
     Fills ``self.flat_grads`` with d(sum_local l / B_global)/d(theta); returns
     (loss tensor[2] = {loss, reg_loss}, pred or None, y_true)."""
-    if self.dropout > 0:
-      raise NotImplementedError('dropout > 0 in training mode is not built yet')
     x, cond = self._split_inputs(data)
     B, T = x.shape[0], x.shape[1] - 1
     if T < 1:
