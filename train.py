@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Thin training driver with the reference's config vocabulary (train.py:22-60 of jirsat/wavenets).
+
+  python train.py --configfile configs/cfg2.yaml                   (1 GPU)
+  python -m torch.distributed.run --nproc-per-node N train.py ...   (data parallel, RCCL)
+
+Keys are the reference's (including the misspelt ``use_resiudal``); ``dataset`` is either
+``synthetic`` (default: SURVEY.md 8d two-tone generator) or a ``.npy`` file of shape (n, samples)
+with waveforms in [-1, 1] (int16 arrays are divided by 2**15).  Checkpoints follow the
+reference's ``weights-e{epoch:04d}-lr{lr}`` naming and resume-from-filename convention."""
+import argparse
+import os
+import sys
+import time
+import wave
+
+import numpy as np
+import torch
+import yaml
+
+config = {                       # defaults of the reference, train.py:22-50
+    'epochs': 500, 'lr': 0.0005, 'recording_length': 8000, 'batch_size': 64, 'apply_mulaw': False,
+    'jit_compile': False, 'dataset': 'synthetic',
+    'kernel_size': 2, 'channels': 32, 'blocks': 5, 'layers_per_block': 5, 'activation': 'leaky_relu',
+    'conditioning': None, 'mapping_layers': [8, 16, 32], 'mapping_activation': 'leaky_relu', 'dropout': 0.1,
+    'dilation_bound': 256, 'num_mixtures': 8, 'sampling_function': 'gaussian', 'bits': 16,
+    'skip_channels': None, 'dilation_channels': None, 'use_resiudal': True, 'use_skip': True,
+    'final_layers_channels': [128, 256], 'l2_reg_factor': 0,
+    # additions of this driver
+    'steps_per_epoch': 0, 'synthetic_utterances': 256, 'sample_rate': 16000, 'results_dir': './results',
+    'preview_length': 0,
+}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--configfile', type=str)
+  ap.add_argument('--epochs', type=int, default=None)
+  args = ap.parse_args()
+  if args.configfile is None:
+    print('No config file provided, using default config')
+    run_name = 'default'
+  else:
+    with open(args.configfile) as f:
+      config.update(yaml.safe_load(f) or {})
+    run_name = os.path.splitext(os.path.basename(args.configfile))[0]
+  if args.epochs is not None:
+    config['epochs'] = args.epochs
+
+  import torch.distributed as dist
+  from wavenets_amd import WaveNet, Adam, callbacks, data, io, ops
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=dev)
+  if config['conditioning'] is not None:
+    raise SystemExit('this driver trains unconditioned models; pass (x, cond) tuples to WaveNet.train_step for '
+                     'global conditioning')
+
+  # ---- data: waveforms -> frames of recording_length + 1 (src/utils.py:22-85) ----
+  L = int(config['recording_length'])
+  if config['dataset'] == 'synthetic':
+    raw = data.synthetic_waveforms(config['synthetic_utterances'], 4 * L + 1, seed=1234)[:, :, 0]
+    raw = ops.inverse_mu_law(raw.to(dev)) if config['apply_mulaw'] else raw.to(dev)
+  else:
+    arr = np.load(config['dataset'])
+    raw = torch.from_numpy(arr)
+    raw = (data.normalise_int16(raw) if arr.dtype == np.int16 else raw.float()).to(dev)
+  frames = torch.cat([data.preprocess_waveform(w, L, config['apply_mulaw']) for w in raw], dim=0)
+  per_rank = config['batch_size'] // world
+  if per_rank < 1 or frames.shape[0] < config['batch_size']:
+    raise SystemExit('not enough data for one global batch')
+  if rank == 0:
+    print(f'{frames.shape[0]} frames of {L + 1} samples; global batch {config["batch_size"]} on {world} GPU(s)')
+
+  model = WaveNet(kernel_size=config['kernel_size'], channels=config['channels'], blocks=config['blocks'],
+                  layers_per_block=config['layers_per_block'], activation=config['activation'],
+                  conditioning=None, mapping_layers=config['mapping_layers'],
+                  mapping_activation=config['mapping_activation'], dropout=config['dropout'],
+                  dilation_bound=config['dilation_bound'], num_mixtures=config['num_mixtures'],
+                  sampling_function=config['sampling_function'], bits=config['bits'],
+                  skip_channels=config['skip_channels'], dilation_channels=config['dilation_channels'],
+                  use_residual=config['use_resiudal'], use_skip=config['use_skip'],
+                  final_layers_channels=config['final_layers_channels'], l2_reg_factor=config['l2_reg_factor'],
+                  device=dev)
+  opt = Adam(learning_rate=config['lr'], clipnorm=1.0)           # train.py:225-226
+  model.compile(optimizer=opt)
+  print('Receptive field') if rank == 0 else None
+  if rank == 0:
+    print(model.receptive_field, ' samples')
+    print(model.compute_receptive_field(config['sample_rate']), ' seconds')
+
+  run_dir = os.path.join(config['results_dir'], run_name)
+  initial_epoch = 0
+  resume = io.find_resume(run_dir)
+  if resume is not None:                                            # train.py:68-86
+    ckpt, initial_epoch, lr = resume
+    io.load_weights(model, ckpt, opt)
+    opt.learning_rate = lr
+    if rank == 0:
+      print(f'resuming from {ckpt} (epoch {initial_epoch}, lr {lr})')
+
+  plateau = callbacks.ReduceLROnPlateau()
+  stopper = callbacks.EarlyStopping()
+  nan_guard = callbacks.TerminateOnNaN()
+  best = float('inf')
+  n_batches = frames.shape[0] // config['batch_size']
+  if config['steps_per_epoch']:
+    n_batches = min(n_batches, int(config['steps_per_epoch']))
+  g = torch.Generator(device='cpu').manual_seed(0)
+  for epoch in range(initial_epoch, config['epochs']):
+    perm = torch.randperm(frames.shape[0], generator=g)          # same permutation on every rank
+    model.loss_tracker.reset_state()
+    t0 = time.time()
+    stop = False
+    for i in range(n_batches):
+      idx = perm[i * config['batch_size']:(i + 1) * config['batch_size']][rank * per_rank:(rank + 1) * per_rank]
+      logs = model.train_step(frames[idx.to(dev)])
+      if nan_guard.on_batch_end(logs['loss']):
+        print('loss is not finite: terminating') if rank == 0 else None
+        stop = True
+        break
+    loss = model.loss_tracker.result()
+    if rank == 0:
+      sps = n_batches * config['batch_size'] * L / max(time.time() - t0, 1e-9)
+      print(f'Epoch {epoch + 1}/{config["epochs"]} - loss: {loss:.4f} - lr: {opt.learning_rate:g} - {sps:,.0f} samples/s')
+      if loss < best:                                               # ModelCheckpoint(save_best_only, monitor='loss')
+        best = loss
+        os.makedirs(run_dir, exist_ok=True)
+        io.save_weights(model, os.path.join(run_dir, io.checkpoint_name(epoch + 1, opt.learning_rate)), opt)
+    plateau.on_epoch_end(loss, opt)
+    if stop or stopper.on_epoch_end(loss, model):
+      break
+
+  # ---- timed generation + dumps (train.py:253-270) ----
+  preview = int(config['preview_length']) or 4 * L
+  if rank == 0:
+    tic = time.time()
+    samples = model.generate(preview, batch_size=min(config['batch_size'], 8), use_queues=config['layers_per_block'] == 1)
+    torch.cuda.synchronize()
+    tictoc = time.time() - tic
+    print(f'Generation took {tictoc}s')
+    print(f'Speed of generation was {preview / tictoc} samples/s')
+    if config['apply_mulaw']:
+      samples = ops.inverse_mu_law(samples)
+    out_dir = os.path.join(run_dir, 'samples')
+    os.makedirs(out_dir, exist_ok=True)
+    arr = samples.cpu().numpy()
+    np.save(os.path.join(out_dir, 'samples.npy'), arr)
+    for i, s in enumerate(arr):
+      with wave.open(os.path.join(out_dir, f'sample_{i}.wav'), 'wb') as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(int(config['sample_rate']))
+        w.writeframes((np.clip(s[:, 0], -1, 1) * 32767).astype('<i2').tobytes())
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

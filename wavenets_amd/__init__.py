@@ -3,6 +3,6 @@ surface of jirsat/wavenets (src/layers.py::WaveNetLayer, src/model.py::WaveNet).
 from .layers import WaveNetLayer
 from .model import WaveNet, MeanSquaredError
 from .optim import Adam
-from . import ops
+from . import ops, dp, io, data, callbacks
 
-__all__ = ['WaveNet', 'WaveNetLayer', 'Adam', 'MeanSquaredError', 'ops']
+__all__ = ['WaveNet', 'WaveNetLayer', 'Adam', 'MeanSquaredError', 'ops', 'dp', 'io', 'data', 'callbacks']
