@@ -46,10 +46,17 @@ struct WnG16 {
 
 // epilogue shared by the streamed and the resident kernels: bias / row bias / residual / activation
 // (or activation derivative, or gate derivative) in registers, then staged full-row stores
-template <int JT, int PITCH>
+// row operands of the epilogue fetched ahead of time (resident kernel): addc, aux (saved activations,
+// or tanh for the gate derivative), aux2 (sigmoid for the gate derivative), all in D layout
+template <int JT>
+struct WnG16Pre {
+  f32x4 addc[JT][4], aux[JT][4], aux2[JT][4];
+};
+
+template <int JT, int PITCH, int PRE = 0>
 __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&acc)[JT], float inv_sc, int jb, int b,
                                                 int t, int64_t row0, int rows_valid, float* stage, int lane,
-                                                float& wmax) {
+                                                float& wmax, const WnG16Pre<JT>* pre = nullptr) {
   const int tl = lane & 31, h = lane >> 5;
   {
     // ---- epilogue in registers (D layout), then staged row stores, 64 channels at a time ----
@@ -80,19 +87,29 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
                 v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
               }
               if (a.addc) {
-                const f32x4 cv = *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0);
+                f32x4 cv;
+                if constexpr (PRE == 1) cv = pre->addc[j < JT ? j : 0][rq];
+                else cv = *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0);
                 v[0] += cv.x; v[1] += cv.y; v[2] += cv.z; v[3] += cv.w;
               }
               if (a.epi == WN_EPI_PLAIN) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], a.act);
               } else if (a.epi == WN_EPI_DACT) {
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                f32x4 yv;
+                if constexpr (PRE == 3) yv = pre->aux[j < JT ? j : 0][rq];
+                else yv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
                 v[0] *= wn_dact_from_y(yv.x, a.act); v[1] *= wn_dact_from_y(yv.y, a.act);
                 v[2] *= wn_dact_from_y(yv.z, a.act); v[3] *= wn_dact_from_y(yv.w, a.act);
               } else {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0);
+                f32x4 av, gv;
+                if constexpr (PRE == 2) {
+                  av = pre->aux[j < JT ? j : 0][rq];
+                  gv = pre->aux2[j < JT ? j : 0][rq];
+                } else {
+                  av = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                  gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0);
+                }
                 if (part == 0) {
                   v[0] *= gv.x * (1.f - av.x * av.x); v[1] *= gv.y * (1.f - av.y * av.y);
                   v[2] *= gv.z * (1.f - av.z * av.z); v[3] *= gv.w * (1.f - av.w * av.w);
@@ -314,7 +331,8 @@ struct WnG16R {
   static constexpr int PF = 4;                                              // k-steps of activations in flight
 };
 
-template <int JT>
+// PREK: which epilogue row operands are fetched ahead: 0 none, 1 addc, 2 gate (tanh | sigmoid)
+template <int JT, int PREK>
 __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmArgs a, const float* w16, int nks_total,
                                                                          const float* absmax_in0, const float* absmax_in1,
                                                                          float* absmax_out) {
@@ -358,49 +376,78 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
   float wmax = 0.f;
   const int tiles_per_b = (a.T + 31) >> 5;
   const int64_t ntiles = (int64_t)a.B * tiles_per_b;
-  for (int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * G::WAVES) {
-    const int b = (int)(tile / tiles_per_b);
-    const int t0 = (int)(tile % tiles_per_b) * 32;
-    const int t = t0 + tl;
-    const int rows_valid = min(32, a.T - t0);
-    const int64_t row0 = (int64_t)b * a.T + t0;
+  // per-tile geometry + row pointers of this lane
+  struct TileCtx {
+    int b, t, rows_valid;
+    int64_t row0;
     const float* xrow_s[WN_MAXSEG];
     bool xok_s[WN_MAXSEG];
+  };
+  auto make_ctx = [&](int64_t tile, TileCtx& c) {
+    c.b = (int)(tile / tiles_per_b);
+    const int t0 = (int)(tile % tiles_per_b) * 32;
+    c.t = t0 + tl;
+    c.rows_valid = min(32, a.T - t0);
+    c.row0 = (int64_t)c.b * a.T + t0;
 #pragma unroll
     for (int s = 0; s < WN_MAXSEG; ++s) {
-      xrow_s[s] = nullptr;
-      xok_s[s] = false;
+      c.xrow_s[s] = nullptr;
+      c.xok_s[s] = false;
       if (s < a.nseg) {
-        const int ts = t - a.seg[s].shift;
-        xok_s[s] = t < a.T && ts >= 0 && ts < a.T;
-        xrow_s[s] = a.seg[s].x + ((int64_t)b * a.T + (xok_s[s] ? ts : 0)) * a.seg[s].ldx + 4 * h;
+        const int ts = c.t - a.seg[s].shift;
+        c.xok_s[s] = c.t < a.T && ts >= 0 && ts < a.T;
+        c.xrow_s[s] = a.seg[s].x + ((int64_t)c.b * a.T + (c.xok_s[s] ? ts : 0)) * a.seg[s].ldx + 4 * h;
       }
     }
-    auto load_x = [&](int ks, f32x4& q0, f32x4& q1) {
-      q0 = f32x4{0.f, 0.f, 0.f, 0.f};
-      q1 = q0;
-      if (ks >= nks_total) return;
-      const float* xr = xrow_s[0];
-      bool ok = xok_s[0];
-      int kk = ks;
+  };
+  auto load_x = [&](const TileCtx& c, int ks, f32x4& q0, f32x4& q1) {
+    q0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    q1 = q0;
+    if (ks >= nks_total) return;
+    const float* xr = c.xrow_s[0];
+    bool ok = c.xok_s[0];
+    int kk = ks;
 #pragma unroll
-      for (int s = 1; s < WN_MAXSEG; ++s)
-        if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }
-      if (ok) {
-        q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
-        q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
-      }
-    };
+    for (int s = 1; s < WN_MAXSEG; ++s)
+      if (ks >= ks_end[s - 1]) { xr = c.xrow_s[s]; ok = c.xok_s[s]; kk = ks - ks_end[s - 1]; }
+    if (ok) {
+      q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
+      q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
+    }
+  };
+  const int64_t tstride = (int64_t)gridDim.x * G::WAVES;
+  int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
+  TileCtx cur;
+  f32x4 xa[PF][2], xb[PF][2];
+  if (tile < ntiles) {
+    make_ctx(tile, cur);
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load_x(cur, k, xa[k][0], xa[k][1]);
+  }
+  for (; tile < ntiles; tile += tstride) {
+    // ---- epilogue operands of THIS tile, issued before the contraction (latency hidden under it) ----
+    WnG16Pre<JT> pre;
+    {
+      const bool tin = cur.t < a.T;
+      const int64_t row = cur.row0 + tl;
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int n0 = 32 * j + 8 * rq + 4 * h;
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (PREK == 1) pre.addc[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0) : z4;
+          if constexpr (PREK == 2) {
+            pre.aux[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0) : z4;
+            pre.aux2[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0) : z4;
+          }
+        }
+    }
     f32x16 acc[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    // activations PF k-steps ahead in two named register sets
-    f32x4 xa[PF][2], xb[PF][2];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) load_x(k, xa[k][0], xa[k][1]);
     auto compute = [&](int ks0, const f32x4 (&xv)[PF][2]) {
 #pragma unroll
       for (int k = 0; k < PF; ++k) {
@@ -418,16 +465,25 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
         }
       }
     };
+    bool x_in_a = true;                                  // which register set holds the last computed chunk
     for (int ks0 = 0; ks0 < nks_total; ks0 += 2 * PF) {
 #pragma unroll
-      for (int k = 0; k < PF; ++k) load_x(ks0 + PF + k, xb[k][0], xb[k][1]);
+      for (int k = 0; k < PF; ++k) load_x(cur, ks0 + PF + k, xb[k][0], xb[k][1]);
       compute(ks0, xa);
       if (ks0 + PF >= nks_total) break;
 #pragma unroll
-      for (int k = 0; k < PF; ++k) load_x(ks0 + 2 * PF + k, xa[k][0], xa[k][1]);
+      for (int k = 0; k < PF; ++k) load_x(cur, ks0 + 2 * PF + k, xa[k][0], xa[k][1]);
       compute(ks0 + PF, xb);
     }
-    wn_g16_epilogue<JT, PITCH>(a, acc, inv_sc, 0, b, t, row0, rows_valid, stage, lane, wmax);
+    (void)x_in_a;
+    // ---- next tile's first activations go in flight before this tile's epilogue and stores ----
+    const TileCtx done = cur;
+    if (tile + tstride < ntiles) {
+      make_ctx(tile + tstride, cur);
+#pragma unroll
+      for (int k = 0; k < PF; ++k) load_x(cur, k, xa[k][0], xa[k][1]);
+    }
+    wn_g16_epilogue<JT, PITCH, PREK>(a, acc, inv_sc, 0, done.b, done.t, done.row0, done.rows_valid, stage, lane, wmax, &pre);
   }
   if (absmax_out) {
 #pragma unroll
@@ -457,7 +513,12 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   const int jt_need = (a.N + 31) / 32;
   // knob 2 = 1 disables the resident form
   if (jt_need == 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1) {
-    hipLaunchKernelGGL(wn_gemm_rows16_resident_kernel<2>, dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    if (a.epi == WN_EPI_GATE_BWD && !a.addc)
+      hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 2>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else if (a.epi == WN_EPI_PLAIN && a.addc)
+      hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 1>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else
+      hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 0>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   } else if (jt_need <= 2) {
     hipLaunchKernelGGL(wn_gemm_rows16_kernel<2>, dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   } else {
