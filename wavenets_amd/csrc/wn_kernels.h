@@ -82,6 +82,11 @@ struct WnWgJob {
   int64_t gmax_off;                          // workspace offset of the running max-abs of g, or < 0
   int32_t ldx, ldg, K, N, shift, k0, n0, pad_;
 };
+// dW_s / db_s of the folded skip path for all blocks (wn_wgrad_skip.hip)
+int wn_wgrad_skip_supported(int D, int S, int KZ);
+int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64_t rows, int KZ, int S, int D,
+                         int nsplit, float* slab, int64_t P, int64_t w_off0, int64_t w_stride, int64_t b_off0,
+                         int64_t b_stride, int nblocks, const float* gmax, hipStream_t s);
 int wn_wgrad_tile_k();
 int wn_wgrad_tile_n();
 int wn_launch_wgrad_batched(const WnWgJob* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,

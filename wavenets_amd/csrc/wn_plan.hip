@@ -78,6 +78,7 @@ struct wn_plan {
   WnTensorDesc* d_cov = nullptr;
   int njobs = 0, ncov = 0, jobs_B = 0, jobs_T = 0, jobs_splits = 0;
   bool jobs_drop = false;
+  bool jobs_skipk = false;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   int prof_used = 0;
@@ -1115,9 +1116,16 @@ void add_jobs(std::vector<WnWgJob>& jobs, int64_t x_off, int ldx, int K, int shi
     }
 }
 
+// the dedicated skip weight-gradient kernel applies to the split-precision path with uniform blocks
+bool skip_kernel_ok(const wn_plan* p) {
+  return p->c.use_skip && p->S > 0 && p->Dp == p->D && p->N >= 1 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
+         wn_debug_get(5) != 1 && wn_wgrad_skip_supported(p->D, p->S, p->N * p->D);
+}
+
 int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
+  const bool skipk = skip_kernel_ok(p);
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
-      p->jobs_drop == (p->drop_rate > 0.f)) return WN_OK;
+      p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk) return WN_OK;
   std::vector<WnWgJob> jobs;
   std::vector<WnTensorDesc> cov;
   auto cover = [&](int t) { WnTensorDesc d; d.off = p->tensors[t].off; d.len = p->tensors[t].len; cov.push_back(d); };
@@ -1146,8 +1154,9 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
              p->tensors[bi.conv1.kernel_t].off, p->tensors[bi.conv1.bias_t].off, p->S == 0 ? am_skip : am_GH(b + 1));
     cover(bi.conv1.kernel_t); cover(bi.conv1.bias_t);
     if (bi.has_skip && p->c.use_skip) {
-      add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, L.g_skipsum, p->S, p->S,
-               p->tensors[bi.conv_skip.kernel_t].off, p->tensors[bi.conv_skip.bias_t].off, am_skip);
+      if (!skipk)
+        add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, L.g_skipsum, p->S, p->S,
+                 p->tensors[bi.conv_skip.kernel_t].off, p->tensors[bi.conv_skip.bias_t].off, am_skip);
       cover(bi.conv_skip.kernel_t); cover(bi.conv_skip.bias_t);
     }
   }
@@ -1166,6 +1175,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   WN_HIP_CHECK(hipMemcpy(p->d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
+  p->jobs_skipk = skipk;
   return WN_OK;
 }
 
@@ -1343,6 +1353,15 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     }
     rc = wn_launch_wgrad_batched(p->d_jobs, p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
     if (rc) return rc;
+    if (p->jobs_skipk) {
+      const BlockInfo& b0 = p->blocks[0];
+      const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
+      const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.bias_t].off - p->tensors[b0.conv_skip.bias_t].off : 0;
+      rc = wn_launch_wgrad_skip(ws + L.Z, p->N * p->Dp, ws + L.g_skipsum, p->S, rows, p->N * p->D, p->S, p->D,
+                                B * L.bsplits, ws + L.bslab, p->nparams, p->tensors[b0.conv_skip.kernel_t].off, wst,
+                                p->tensors[b0.conv_skip.bias_t].off, bst, p->N, am_gskip, s);
+      if (rc) return rc;
+    }
     rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov, p->ncov, s);
     if (rc) return rc;
     if (!p->c.use_skip && p->S > 0) {
