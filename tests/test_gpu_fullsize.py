@@ -1,0 +1,108 @@
+"""Full-size checks at BASELINE.json configs[1] (30-layer, 64/256 channels, batch 8 x 16000) where the
+CPU oracle is too slow: size-independent properties of the HIP path.
+
+ * directional derivative: (L(theta + eps v) - L(theta - eps v)) / (2 eps) == <grad, v>
+ * batch linearity (the data-parallel contract): grads(A) + grads(B) == grads(A u B) under the
+   global-batch loss scaling (src/model.py:328-329)
+ * determinism: identical inputs -> bit-identical loss and gradients
+ * both math modes agree within the activation tolerance
+ * queued generation == sliding window at the full receptive field (3071)
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG2 = dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024,
+            final_layers_channels=[128, 256], activation='leaky_relu', bits=8)
+
+
+def dev():
+  return torch.device('cuda', 0)
+
+
+@pytest.fixture(scope='module')
+def setup():
+  from wavenets_amd import WaveNet
+  from oracle import wavenet_oracle as O          # synthetic input generator only
+  model = WaveNet(**CFG2, device=dev(), seed=3)
+  g = torch.Generator().manual_seed(0)
+  with torch.no_grad():                           # non-zero biases (Keras zeros would hide bias bugs)
+    for n, t in zip(model.variable_names, model.trainable_variables):
+      if n.endswith('bias'):
+        t.copy_(((torch.rand(t.shape, generator=g) * 2 - 1) * 0.05).to(dev()))
+  x = O.synthetic_waveform(8, 16001, seed=77).to(dev())
+  return model, x
+
+
+def test_directional_derivative(setup):
+  model, x = setup
+  loss, _, _ = model.loss_and_grads(x)
+  grads = model.flat_grads.clone()
+  g = torch.Generator().manual_seed(1)
+  v = torch.randn(grads.numel(), generator=g).to(dev())
+  v = v / v.norm()
+  theta = model.flat_params.data.clone()
+  eps = 2e-3
+  vals = []
+  for sgn in (1.0, -1.0):
+    model.flat_params.data.copy_(theta + sgn * eps * v)
+    vals.append(model.test_step(x)['loss'])
+    model.loss_tracker.reset_state()
+  model.flat_params.data.copy_(theta)
+  fd = (vals[0] - vals[1]) / (2 * eps)
+  an = float(torch.dot(grads.double(), v.double()))
+  # loss ~ 9e4 in fp32 (resolution ~1e-2): the finite difference itself is good to ~1e-2 / 4e-3
+  assert abs(fd - an) < 2e-3 * max(1.0, abs(an)) + 5.0, (fd, an)
+
+
+def test_batch_linearity_and_determinism(setup):
+  model, x = setup
+  l_all, _, _ = model.loss_and_grads(x, global_batch=8, n_replicas=1)
+  g_all = model.flat_grads.clone()
+  l_again, _, _ = model.loss_and_grads(x, global_batch=8, n_replicas=1)
+  assert torch.equal(l_all, l_again) and torch.equal(g_all, model.flat_grads)      # deterministic
+  acc, ltot = torch.zeros_like(g_all), 0.0
+  for part in (x[:3], x[3:]):
+    l, _, _ = model.loss_and_grads(part, global_batch=8, n_replicas=2)
+    acc += model.flat_grads
+    ltot += l[0].item()
+  assert abs(ltot - l_all[0].item()) < 1e-5 * abs(l_all[0].item())
+  scale = g_all.abs().max().item()
+  assert (acc - g_all).abs().max().item() < 1e-4 * scale
+
+
+def test_math_modes_agree(setup):
+  from wavenets_amd import _lib
+  model, x = setup
+  inp = x[:2, :4096]
+  a = model.logits(inp)
+  _lib.lib().wn_debug_set(1, 1)
+  try:
+    b = model.logits(inp)
+  finally:
+    _lib.lib().wn_debug_set(1, 0)
+  assert (a - b).abs().max().item() < 1e-4
+
+
+def test_queued_equals_naive_full_receptive_field(setup):
+  model, x = setup
+  rf = model.receptive_field
+  assert rf == 3071
+  w = x[:4, :rf]
+  naive = model.generate(6, sample=w, use_queues=False, deterministic=True)
+  queued = model.generate(6, sample=w, use_queues=True, deterministic=True)
+  assert torch.equal(naive, queued)
+
+
+def test_train_steps_reduce_loss(setup):
+  from wavenets_amd import Adam, WaveNet
+  _, x = setup
+  model = WaveNet(**CFG2, device=dev(), seed=5)
+  model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
+  first = model.train_step(x)['loss']
+  for _ in range(5):
+    last = model.train_step(x)
+  model.loss_tracker.reset_state()
+  final = model.test_step(x)['loss']
+  assert final < first and torch.isfinite(torch.tensor(final))
