@@ -98,6 +98,14 @@ __device__ __forceinline__ void wn_static_for(F&& f) {
     }                                                        \
   } while (0)
 
+// gate derivative from the saved sigmoid g and z = tanh * g:  a = z / g (g > 0; when g underflowed both
+// derivatives vanish anyway);  d/du_f = dz * g * (1 - a^2),  d/du_g = dz * a * g * (1 - g) = dz * z * (1 - g)
+__device__ __forceinline__ void wn_gate_bwd(float dz, float g, float z, float& duf, float& dug) {
+  const float a = g > 1e-30f ? z / g : 0.f;
+  duf = dz * g * (1.f - a * a);
+  dug = dz * z * (1.f - g);
+}
+
 // running max-abs of a tensor (non-negative floats order like their bit patterns); the plain read
 // first keeps almost every wave off the atomic (one address: contention would serialise them)
 __device__ __forceinline__ void wn_absmax_publish(float* slot, float v) {

@@ -564,7 +564,7 @@ __global__ void wn_gate_kernel(const float* u, int64_t rows, int D, float* ag, f
     const int c = (int)(i % D);
     const float a = wn_tanh_fast(u[r * 2 * D + c]);
     const float g = wn_sigmoid_fast(u[r * 2 * D + D + c]);
-    if (ag) { ag[r * 2 * D + c] = a; ag[r * 2 * D + D + c] = g; }
+    if (ag) ag[r * D + c] = g;          // saved sigmoid only (tanh = z / sigmoid in backward)
     if (z) z[r * ldz + c] = a * g;
   }
 }

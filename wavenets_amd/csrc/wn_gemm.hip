@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256, (JT >= 8 ? 2 : (JT >= 4 ? 3 : 4))) void wn_gem
     const float* sx = a.seg[s].x;
     const float* sfrag = a.seg[s].frag;
     const int sldx = a.seg[s].ldx, sK = a.seg[s].K, sshift = a.seg[s].shift, svec = a.seg[s].vec;
+    const int splk = a.seg[s].plane_k;
+    const int64_t splst = a.seg[s].plane_stride;
     const int ts = t - sshift;
     const bool valid = (t < a.T) && (ts >= 0) && (ts < a.T);
     const float* xrow = sx + ((int64_t)b * a.T + (valid ? ts : 0)) * sldx;
@@ -148,13 +150,15 @@ __global__ __launch_bounds__(256, (JT >= 8 ? 2 : (JT >= 4 ? 3 : 4))) void wn_gem
       const int k = 8 * q + 4 * h;
       f32x4 xv = {0.f, 0.f, 0.f, 0.f};
       if (valid) {
+        // block-major operands: channel k lives in plane k / plane_k (plane_k is a multiple of 8)
+        const float* xp = splk > 0 ? xrow + (int64_t)(k / splk) * splst + (k % splk) : xrow + k;
         if (svec && k + 3 < sK) {
-          xv = *reinterpret_cast<const f32x4*>(xrow + k);
+          xv = *reinterpret_cast<const f32x4*>(xp);
         } else {
-          if (k + 0 < sK) xv.x = xrow[k + 0];
-          if (k + 1 < sK) xv.y = xrow[k + 1];
-          if (k + 2 < sK) xv.z = xrow[k + 2];
-          if (k + 3 < sK) xv.w = xrow[k + 3];
+          if (k + 0 < sK) xv.x = xp[0];
+          if (k + 1 < sK) xv.y = xp[1];
+          if (k + 2 < sK) xv.z = xp[2];
+          if (k + 3 < sK) xv.w = xp[3];
         }
       }
       return xv;
@@ -231,13 +235,14 @@ __global__ __launch_bounds__(256, (JT >= 8 ? 2 : (JT >= 4 ? 3 : 4))) void wn_gem
           o.z = v[2] * wn_dact_from_y(yv.z, a.act); o.w = v[3] * wn_dact_from_y(yv.w, a.act);
           *reinterpret_cast<f32x4*>(a.y + row * a.ldy + n0) = o;
         } else {  // WN_EPI_GATE_BWD
-          const f32x4 av = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0);
-          f32x4 of, og;
-          of.x = v[0] * gv.x * (1.f - av.x * av.x); og.x = v[0] * av.x * gv.x * (1.f - gv.x);
-          of.y = v[1] * gv.y * (1.f - av.y * av.y); og.y = v[1] * av.y * gv.y * (1.f - gv.y);
-          of.z = v[2] * gv.z * (1.f - av.z * av.z); og.z = v[2] * av.z * gv.z * (1.f - gv.z);
-          of.w = v[3] * gv.w * (1.f - av.w * av.w); og.w = v[3] * av.w * gv.w * (1.f - gv.w);
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+          const f32x4 zv = *reinterpret_cast<const f32x4*>(a.aux2 + row * a.ld_aux2 + n0);
+          float f4[4], g4[4];
+          wn_gate_bwd(v[0], gv.x, zv.x, f4[0], g4[0]);
+          wn_gate_bwd(v[1], gv.y, zv.y, f4[1], g4[1]);
+          wn_gate_bwd(v[2], gv.z, zv.z, f4[2], g4[2]);
+          wn_gate_bwd(v[3], gv.w, zv.w, f4[3], g4[3]);
+          const f32x4 of = {f4[0], f4[1], f4[2], f4[3]}, og = {g4[0], g4[1], g4[2], g4[3]};
           *reinterpret_cast<f32x4*>(a.y + row * a.ldy + n0) = of;
           *reinterpret_cast<f32x4*>(a.y + row * a.ldy + a.N + n0) = og;
         }
@@ -255,10 +260,10 @@ __global__ __launch_bounds__(256, (JT >= 8 ? 2 : (JT >= 4 ? 3 : 4))) void wn_gem
           } else if (a.epi == WN_EPI_DACT) {
             a.y[row * a.ldy + n] = w * wn_dact_from_y(a.aux[row * a.ld_aux + n], a.act);
           } else {
-            const float av = a.aux[row * a.ld_aux + n];
-            const float gv = a.aux[row * a.ld_aux + a.N + n];
-            a.y[row * a.ldy + n] = w * gv * (1.f - av * av);
-            a.y[row * a.ldy + a.N + n] = w * av * gv * (1.f - gv);
+            float duf, dug;
+            wn_gate_bwd(w, a.aux[row * a.ld_aux + n], a.aux2[row * a.ld_aux2 + n], duf, dug);
+            a.y[row * a.ldy + n] = duf;
+            a.y[row * a.ldy + a.N + n] = dug;
           }
         }
       }

@@ -102,21 +102,19 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
                 v[0] *= wn_dact_from_y(yv.x, a.act); v[1] *= wn_dact_from_y(yv.y, a.act);
                 v[2] *= wn_dact_from_y(yv.z, a.act); v[3] *= wn_dact_from_y(yv.w, a.act);
               } else {
-                f32x4 av, gv;
+                f32x4 gv, zv;        // saved sigmoid, gated activation
                 if constexpr (PRE == 2) {
-                  av = pre->aux[j < JT ? j : 0][rq];
-                  gv = pre->aux2[j < JT ? j : 0][rq];
+                  gv = pre->aux[j < JT ? j : 0][rq];
+                  zv = pre->aux2[j < JT ? j : 0][rq];
                 } else {
-                  av = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
-                  gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0);
+                  gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                  zv = *reinterpret_cast<const f32x4*>(a.aux2 + row * a.ld_aux2 + n0);
                 }
-                if (part == 0) {
-                  v[0] *= gv.x * (1.f - av.x * av.x); v[1] *= gv.y * (1.f - av.y * av.y);
-                  v[2] *= gv.z * (1.f - av.z * av.z); v[3] *= gv.w * (1.f - av.w * av.w);
-                } else {
-                  v[0] *= av.x * gv.x * (1.f - gv.x); v[1] *= av.y * gv.y * (1.f - gv.y);
-                  v[2] *= av.z * gv.z * (1.f - gv.z); v[3] *= av.w * gv.w * (1.f - gv.w);
-                }
+                float duf, dug;
+                wn_gate_bwd(v[0], gv.x, zv.x, duf, dug); v[0] = part == 0 ? duf : dug;
+                wn_gate_bwd(v[1], gv.y, zv.y, duf, dug); v[1] = part == 0 ? duf : dug;
+                wn_gate_bwd(v[2], gv.z, zv.z, duf, dug); v[2] = part == 0 ? duf : dug;
+                wn_gate_bwd(v[3], gv.w, zv.w, duf, dug); v[3] = part == 0 ? duf : dug;
               }
               wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             }
@@ -208,6 +206,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
     // per-segment row pointer of this lane (hoisted: the chunk loop then needs no segment fields)
     const float* xrow_s[WN_MAXSEG];
     bool xok_s[WN_MAXSEG];
+    const int plane_ks0 = a.seg[0].plane_k > 0 ? a.seg[0].plane_k / 16 : 0;     // only segment 0 may be planar
+    const int64_t plane_st0 = a.seg[0].plane_stride;
 #pragma unroll
     for (int s = 0; s < WN_MAXSEG; ++s) {
       xrow_s[s] = nullptr;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
       for (int s = 1; s < WN_MAXSEG; ++s)
         if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }   // wave-uniform
       if (ok) {
+        if (plane_ks0 > 0 && ks < ks_end[0]) xr += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
         q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
         q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
       }
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
           if constexpr (PREK == 1) pre.addc[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0) : z4;
           if constexpr (PREK == 2) {
             pre.aux[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0) : z4;
-            pre.aux2[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + a.N + n0) : z4;
+            pre.aux2[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.aux2 + row * a.ld_aux2 + n0) : z4;
           }
         }
     }
@@ -496,8 +497,10 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
 int wn_gemm_rows16_ok(const WnGemmArgs& a) {
   if (a.N % 32 != 0 || a.N < 64) return 0;
   if (!a.vec_out) return 0;
-  for (int s = 0; s < a.nseg; ++s)
+  for (int s = 0; s < a.nseg; ++s) {
     if (a.seg[s].K % 16 != 0 || !a.seg[s].vec) return 0;
+    if (a.seg[s].plane_k > 0 && (s != 0 || a.seg[s].plane_k % 16 != 0)) return 0;
+  }
   if (a.rowbias && (a.ld_rowbias % 4 != 0)) return 0;
   return 1;
 }
@@ -512,7 +515,8 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   if (gx > 256) gx = 256;
   const int jt_need = (a.N + 31) / 32;
   // knob 2 = 1 disables the resident form
-  if (jt_need == 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1) {
+  if (jt_need == 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1 &&
+      a.seg[0].plane_k == 0) {
     if (a.epi == WN_EPI_GATE_BWD && !a.addc)
       hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 2>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
     else if (a.epi == WN_EPI_PLAIN && a.addc)

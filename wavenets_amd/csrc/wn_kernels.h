@@ -36,6 +36,8 @@ struct WnSeg {
   int32_t K;          // valid channels of this segment
   int32_t shift;      // output row t contracts x row t - shift (zero outside [0,T))
   int32_t vec;        // 1: rows are 16-byte aligned and K % 4 == 0 -> vector loads
+  int32_t plane_k;    // > 0: the K channels are spread over planes of plane_k channels, plane p at x + p * plane_stride
+  int64_t plane_stride;   // (block-major Z: [N][rows][D]); ldx is then the row stride inside a plane
 };
 struct WnGemmArgs {
   WnSeg seg[WN_MAXSEG];
@@ -50,8 +52,10 @@ struct WnGemmArgs {
   int32_t ld_addc;
   int32_t act;
   int32_t epi;
-  const float* aux;       // WN_EPI_DACT: saved activations; WN_EPI_GATE_BWD: saved (a | g)
+  const float* aux;       // WN_EPI_DACT: saved activations; WN_EPI_GATE_BWD: saved sigmoid g [rows][ld_aux]
   int32_t ld_aux;
+  const float* aux2;      // WN_EPI_GATE_BWD: gated activation z = tanh * sigmoid [rows][ld_aux2]
+  int32_t ld_aux2;
   float* y;
   int32_t ldy;
   int32_t vec_out;        // 1: y/addc/aux rows 16-byte aligned, N % 4 == 0
@@ -112,7 +116,7 @@ struct WnLayerFwdArgs {
   float* x_out;          // [B*T][R]
   float* o_out;          // [B*T][R] pre-residual output (skip when skip_channels is None) or null
   float* z_out; int32_t ldz;   // gated activations, row stride ldz, or null
-  float* ag_out;         // [B*T][2D] saved tanh | sigmoid, or null
+  float* ag_out;         // [B*T][D] saved sigmoid (tanh is recovered as z / sigmoid in backward), or null
   const float* res;      // residual source [B*T][R] when it is not the conv input (depth > 1), or null
   const float* xt[3];    // queued generation: tap j reads rows of xt[j] (no time shift) instead of x; or null
   int32_t B, T, R, D, KS, dilation, residual;

@@ -161,10 +161,7 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
       u[j][4 * rq + 2] = zv.z; u[j][4 * rq + 3] = zv.w;
       const int n0 = 32 * j + 8 * rq + 4 * h;
       if (tin && !(VAR & 4)) {
-        if (a.ag_out) {
-          *reinterpret_cast<f32x4*>(a.ag_out + row * 2 * D + n0) = av;
-          *reinterpret_cast<f32x4*>(a.ag_out + row * 2 * D + D + n0) = gv;
-        }
+        if (a.ag_out) *reinterpret_cast<f32x4*>(a.ag_out + row * D + n0) = gv;
         if (a.z_out) *reinterpret_cast<f32x4*>(a.z_out + row * a.ldz + n0) = zv;
       }
     }

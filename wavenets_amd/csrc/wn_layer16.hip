@@ -164,21 +164,19 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
     //      u[j] (filter) -> z, u[j + D32] (gate) -> sigmoid; tanh kept in a separate tile set only
     //      while it is being written out
     if (a.ag_out) {
-      f32x16 av[D32];
+      // the sigmoid tile is saved for backward (tanh is recovered there as z / sigmoid)
 #pragma unroll
       for (int j = 0; j < D32; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          av[j][r] = wn_tanh_fast(u[j][r]);
           u[j + D32][r] = wn_sigmoid_fast(u[j + D32][r]);
-          u[j][r] = av[j][r] * u[j + D32][r];
+          u[j][r] = wn_tanh_fast(u[j][r]) * u[j + D32][r];
         }
       if (rows_valid > 0) {
-        wn_store_tile<D32, PITCH>(av, stage, a.ag_out + row0 * 2 * D, 2 * D, rows_valid, lane);
         f32x16 gv[D32];
 #pragma unroll
         for (int j = 0; j < D32; ++j) gv[j] = u[j + D32];
-        wn_store_tile<D32, PITCH>(gv, stage, a.ag_out + row0 * 2 * D + D, 2 * D, rows_valid, lane);
+        wn_store_tile<D32, PITCH>(gv, stage, a.ag_out + row0 * D, D, rows_valid, lane);
       }
     } else {
 #pragma unroll

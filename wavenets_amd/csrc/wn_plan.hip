@@ -206,7 +206,7 @@ struct WsLayout {
   std::vector<int64_t> H;               // N+1 block inputs/outputs (training) or 2 (inference)
   std::vector<std::vector<int64_t>> P;  // per block: outputs of the non-gated convs (depth > 1)
   int64_t Z;                            // [rows][N*Dp]
-  std::vector<int64_t> AG;              // per block [rows][2D] (training)
+  std::vector<int64_t> AG;              // per block [rows][D] saved sigmoid (training)
   int64_t U;                            // [rows][2D] scratch of the composed path / g_u
   int64_t O;                            // [rows][R] pre-residual output scratch
   int64_t skipsum;                      // [rows][Hin]
@@ -273,7 +273,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     for (int b = 0; b < p->N; ++b) L.P[b] = tmp[training ? b : 0];
   }
   L.Z = cv.take(rows * p->N * p->Dp);
-  if (training) for (int b = 0; b < p->N; ++b) L.AG.push_back(cv.take(rows * 2 * p->D));
+  if (training) for (int b = 0; b < p->N; ++b) L.AG.push_back(cv.take(rows * p->D));
   L.U = cv.take(rows * 2 * p->D);
   L.O = cv.take(rows * p->R);
   L.skipsum = cv.take(rows * p->Hin);
@@ -373,6 +373,15 @@ struct Gemm {
     WnSeg& s = a.seg[a.nseg++];
     s.x = x; s.ldx = ldx; s.K = K; s.shift = shift; s.frag = frag;
     s.vec = (ldx % 4 == 0 && K % 4 == 0 && al16(x)) ? 1 : 0;
+    s.plane_k = 0; s.plane_stride = 0;
+    return *this;
+  }
+  // block-major operand [K / plane_k][rows][plane_k] (the gated activations Z of all blocks)
+  Gemm& seg_planes(const float* x, int plane_k, int64_t plane_stride, int K, const float* frag) {
+    seg(x, plane_k, K, 0, frag);
+    WnSeg& s = a.seg[a.nseg - 1];
+    s.plane_k = plane_k; s.plane_stride = plane_stride;
+    s.vec = (plane_k % 4 == 0 && plane_stride % 4 == 0 && al16(x)) ? 1 : 0;
     return *this;
   }
   Gemm& bias(const float* b) { a.bias = b; return *this; }
@@ -380,13 +389,17 @@ struct Gemm {
   Gemm& addc(const float* c, int ld) { a.addc = c; a.ld_addc = ld; return *this; }
   Gemm& act(int act) { a.act = act; return *this; }
   Gemm& dact(const float* ysaved, int ld, int act) { a.epi = WN_EPI_DACT; a.aux = ysaved; a.ld_aux = ld; a.act = act; return *this; }
-  Gemm& gate_bwd(const float* ag, int ld) { a.epi = WN_EPI_GATE_BWD; a.aux = ag; a.ld_aux = ld; return *this; }
+  Gemm& gate_bwd(const float* g, int ldg, const float* z, int ldz) {
+    a.epi = WN_EPI_GATE_BWD; a.aux = g; a.ld_aux = ldg; a.aux2 = z; a.ld_aux2 = ldz;
+    return *this;
+  }
   int run(float* y, int ldy, hipStream_t s) {
     a.y = y; a.ldy = ldy;
     bool v = (a.N % 4 == 0) && (ldy % 4 == 0) && al16(y);
     if (a.bias) v = v && al16(a.bias);
     if (a.addc) v = v && (a.ld_addc % 4 == 0) && al16(a.addc);
     if (a.aux) v = v && (a.ld_aux % 4 == 0) && al16(a.aux);
+    if (a.aux2) v = v && (a.ld_aux2 % 4 == 0) && al16(a.aux2);
     a.vec_out = v ? 1 : 0;
     // knob 1 = 1 forces the exact-fp32 MFMA kernels
     if (w16_ && wn_debug_get(1) != 1 && wn_gemm_rows16_ok(a)) return wn_launch_gemm_rows16(a, w16_, am0_, am1_, amo_, s);
@@ -459,7 +472,7 @@ struct BlockBufs {
   const float* x;           // [rows][Cin]
   float* P[16];             // outputs of non-gated convs [rows][D]
   float* U;                 // [rows][2D] scratch
-  float* AG;                // [rows][2D] saved (a|g) or null
+  float* AG;                // [rows][D] saved sigmoid or null
   float* Z; int ldz;        // gated activations
   float* O;                 // [rows][R] pre-residual output or null
   float* x_out;             // [rows][R]
@@ -566,7 +579,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     if (use_gzs) gm.addc(g.gzs, g.ld_gzs).w16(k.G16r).absmax(g.am_gxout, nullptr, g.am_gu);
     else if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, k.Bs);
     if (use_gzs) {
-      rc = gm.gate_bwd(f.AG, 2 * k.D).run(g.g_u, 2 * k.D, s);
+      rc = gm.gate_bwd(f.AG, k.D, f.Z, f.ldz).run(g.g_u, 2 * k.D, s);
     } else if (gm.a.nseg == 0) {
       rc = wn_launch_fill(g.g_u, 0.f, rows * 2 * k.D, s);
     } else {
@@ -577,7 +590,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
         const float* a1 = (k.S > 0 || g_o == g.g_o_tmp) ? g.am_gskip : nullptr;
         if (g.am_gu && a0) gm.w16(k.G16u).absmax(a0, a1, g.am_gu);
       }
-      rc = gm.gate_bwd(f.AG, 2 * k.D).run(g.g_u, 2 * k.D, s);
+      rc = gm.gate_bwd(f.AG, k.D, f.Z, f.ldz).run(g.g_u, 2 * k.D, s);
     }
     if (rc) return rc;
   }
@@ -1033,7 +1046,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
     f.U = ws + L.U;
     f.AG = training ? ws + L.AG[b] : nullptr;
-    f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+    f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;      // block-major [N][rows][Dp]
     f.O = nullptr;
     f.x_out = ws + L.H[ho];
     const bool prof = p->prof_on && p->prof_used + 2 <= (int)p->prof_ev.size();
@@ -1050,7 +1063,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   // with src/layers.py:216-219), or the last block output when use_skip is False
   const float* hin;
   if (p->c.use_skip) {
-    rc = Gemm(B, T, p->Sh, ceil32(p->Sh)).seg(ws + L.Z, p->N * p->Dp, p->N * p->Dp, 0, fragbase + p->frag_skipF)
+    rc = Gemm(B, T, p->Sh, ceil32(p->Sh)).seg_planes(ws + L.Z, p->Dp, rows * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
              .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
              .bias(ws + L.bias_sum).run(ws + L.skipsum, p->Sh, s);
     if (rc) return rc;
@@ -1148,14 +1161,14 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
                p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D,
                t == p->KS - 1 ? p->tensors[c.bias_t].off : -1, am_GU(b));
     cover(c.kernel_t); cover(c.bias_t);
-    const int64_t zoff = L.Z + (int64_t)b * p->Dp;
+    const int64_t zoff = L.Z + (int64_t)b * B * T * p->Dp;      // block-major Z
     // S == 0: g_o = g_xout + g_skip (or a copy of g_skip): bounded by twice the larger max-abs -> no slot
-    add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, p->S == 0 ? L.GO[b] : L.GH[b + 1], p->R, p->R,
+    add_jobs(jobs, zoff, p->Dp, p->D, 0, p->S == 0 ? L.GO[b] : L.GH[b + 1], p->R, p->R,
              p->tensors[bi.conv1.kernel_t].off, p->tensors[bi.conv1.bias_t].off, p->S == 0 ? am_skip : am_GH(b + 1));
     cover(bi.conv1.kernel_t); cover(bi.conv1.bias_t);
     if (bi.has_skip && p->c.use_skip) {
       if (!skipk)
-        add_jobs(jobs, zoff, p->N * p->Dp, p->D, 0, L.g_skipsum, p->S, p->S,
+        add_jobs(jobs, zoff, p->Dp, p->D, 0, L.g_skipsum, p->S, p->S,
                  p->tensors[bi.conv_skip.kernel_t].off, p->tensors[bi.conv_skip.bias_t].off, am_skip);
       cover(bi.conv_skip.kernel_t); cover(bi.conv_skip.bias_t);
     }
@@ -1321,7 +1334,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       memset(&f, 0, sizeof(f));
       f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
       f.AG = ws + L.AG[b];
-      f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+      f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;
       BlockGrads bg;
       memset(&bg, 0, sizeof(bg));
       bg.defer = true;
@@ -1357,7 +1370,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       const BlockInfo& b0 = p->blocks[0];
       const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
       const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.bias_t].off - p->tensors[b0.conv_skip.bias_t].off : 0;
-      rc = wn_launch_wgrad_skip(ws + L.Z, p->N * p->Dp, ws + L.g_skipsum, p->S, rows, p->N * p->D, p->S, p->D,
+      rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.g_skipsum, p->S, rows, p->N * p->D, p->S, p->D,
                                 B * L.bsplits, ws + L.bslab, p->nparams, p->tensors[b0.conv_skip.kernel_t].off, wst,
                                 p->tensors[b0.conv_skip.bias_t].off, bst, p->N, am_gskip, s);
       if (rc) return rc;
@@ -1402,7 +1415,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
     for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
     f.AG = ws + L.AG[b];
-    f.Z = ws + L.Z + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+    f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;
     BlockGrads bg;
     memset(&bg, 0, sizeof(bg));
     if (p->drop_rate > 0.f) {
@@ -1659,7 +1672,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       f.x = f.xt[p->KS - 1];
       f.U = workspace + G.hrow1;
       f.AG = nullptr;
-      f.Z = Zrow + (int64_t)b * p->Dp; f.ldz = p->N * p->Dp;
+      f.Z = Zrow + (int64_t)b * B * p->Dp; f.ldz = p->Dp;
       f.O = nullptr;
       f.x_out = (b + 1 < p->N) ? R.h[b + 1] + (int64_t)(tau % R.nslots[b + 1]) * B * p->R
                                : (p->c.use_skip ? workspace + G.dummy : workspace + G.hrow0);
@@ -1668,7 +1681,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     }
     const float* hin;
     if (p->c.use_skip) {
-      rc = Gemm(B, 1, p->Sh, ceil32(p->Sh)).seg(Zrow, p->N * p->Dp, p->N * p->Dp, 0, fragbase + p->frag_skipF)
+      rc = Gemm(B, 1, p->Sh, ceil32(p->Sh)).seg_planes(Zrow, p->Dp, (int64_t)B * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
                .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
                .bias(pws + L.bias_sum).run(workspace + G.skiprow, p->Sh, s);
       if (rc) return rc;
@@ -1770,7 +1783,7 @@ int layer_layout(const wn_layer_desc* d, int B, int T, LayerLayout& L) {
   L.ws_total = cv.pos;
   Carver sv;
   for (int i = 0; i + 1 < d->depth; ++i) L.sP[i] = sv.take(rows * D);
-  L.sAG = sv.take(rows * 2 * D);
+  L.sAG = sv.take(rows * D);
   L.sZ = sv.take(rows * D);
   L.saved_total = sv.pos;
   return WN_OK;

@@ -16,7 +16,7 @@
 typedef _Float16 ws_h8 __attribute__((ext_vector_type(8)));
 
 struct WnWgSkipArgs {
-  const float* z; int32_t ldz;          // [rows][ldz], ldz = N*D
+  const float* z; int32_t ldz;          // block-major [N][rows][D]: ldz = D, plane stride = rows * D
   const float* g; int32_t ldg;          // [rows][S]
   int64_t rows;
   int32_t KZ;                           // N*D
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_skip_kernel(WnWgSkipArgs a) {
   // exactly one wave: waves 0..NT-1 produce g tiles 0..NT-1 (NT <= 8)
   const bool makes_g = wave < NT;
   const int ncol = wave * 32 + tl;                          // g column when makes_g
-  const float* zbase = a.z + kcol;
+  const float* zbase = a.z + (int64_t)(kcol / a.D) * a.rows * a.D + (kcol % a.D);   // column kcol -> (block, channel)
   const float* gbase = a.g + ncol;
   auto load = [&](int64_t rr, float (&zv)[8], float (&gv)[8]) {
     const int64_t rb = rr + 8 * h;
