@@ -86,11 +86,19 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if args.gpus > 1 and world != args.gpus:
     raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  # WN_BENCH_BACKEND=gloo lets several ranks share ONE GPU (rehearsal of the multi-rank path on a
+  # single-GPU box); the measured configuration is always nccl (= RCCL), one rank per GPU
+  backend = os.environ.get('WN_BENCH_BACKEND', 'nccl')
+  ndev = torch.cuda.device_count()
+  dev_index = local_rank % max(ndev, 1) if backend != 'nccl' else local_rank
+  torch.cuda.set_device(dev_index)
+  dev = torch.device('cuda', dev_index)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=dev)
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=dev)
+    else:
+      dist.init_process_group(backend)
 
   B, T = args.batch, args.length
   model = WaveNet(**CFG2, device=dev, seed=0)          # glorot kernels, zero biases, same on all ranks

@@ -37,23 +37,39 @@ int wn_launch_fill(float* p, float v, int64_t n, hipStream_t s) {
   return WN_OK;
 }
 
-// out[b][c] = sum_t g[b][t][c]
-__global__ void wn_colsum_kernel(const float* g, int T, int C, float* out) {
-  __shared__ double part[256];
-  const int b = blockIdx.x;
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+// out[b][c] = sum_t g[b][t][c]: stage 1 sums WN_CS_CHUNKS time chunks per utterance in parallel
+// (one block per (utterance, chunk, 64 channels)), stage 2 folds the chunks in a fixed order.
+#define WN_CS_CHUNKS 128
+__global__ void wn_colsum_stage1(const float* g, int T, int C, float* part) {
+  __shared__ float sm[256];
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int c = blockIdx.z * 64 + (threadIdx.x & 63);
   const int p = threadIdx.x >> 6;
-  double acc = 0.0;
+  const int len = (T + WN_CS_CHUNKS - 1) / WN_CS_CHUNKS;
+  const int t0 = chunk * len, t1 = min(T, t0 + len);
+  float acc = 0.f;
   if (c < C)
-    for (int t = p; t < T; t += 4) acc += (double)g[((int64_t)b * T + t) * C + c];
-  part[threadIdx.x] = acc;
+    for (int t = t0 + p; t < t1; t += 4) acc += g[((int64_t)b * T + t) * C + c];
+  sm[threadIdx.x] = acc;
   __syncthreads();
   if (p == 0 && c < C)
-    out[(int64_t)b * C + c] = (float)(part[threadIdx.x] + part[threadIdx.x + 64] +
-                                      part[threadIdx.x + 128] + part[threadIdx.x + 192]);
+    part[((int64_t)b * WN_CS_CHUNKS + chunk) * C + c] = sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192];
 }
-int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(wn_colsum_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, s, g, T, C, out);
+__global__ void wn_colsum_stage2(const float* part, int C, float* out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / C;
+  const int c = (int)(i % C);
+  double acc = 0.0;
+  for (int k = 0; k < WN_CS_CHUNKS; ++k) acc += (double)part[(b * WN_CS_CHUNKS + k) * C + c];
+  out[i] = (float)acc;
+}
+// scratch: B * WN_CS_CHUNKS * C floats
+int64_t wn_colsum_scratch_floats(int B, int C) { return (int64_t)B * WN_CS_CHUNKS * C; }
+int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(wn_colsum_stage1, dim3(B, WN_CS_CHUNKS, (C + 63) / 64), dim3(256), 0, s, g, T, C, scratch);
+  const int64_t total = (int64_t)B * C;
+  hipLaunchKernelGGL(wn_colsum_stage2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, C, out, total);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

@@ -137,7 +137,8 @@ int wn_launch_dropout(const float* x, const float* g_res, float* out, int64_t n,
                       float* absmax_out, hipStream_t s);
 int wn_launch_gate(const float* u, int64_t rows, int D, float* ag, float* z, int ldz, hipStream_t s);
 int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s);
-int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, hipStream_t s);
+int64_t wn_colsum_scratch_floats(int B, int C);
+int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, float* scratch, hipStream_t s);
 int wn_launch_quantize(const float* x, int32_t* idx, int64_t n, int bits, hipStream_t s);
 int wn_launch_dequantize(const int32_t* idx, float* x, int64_t n, int bits, hipStream_t s);
 int wn_launch_mulaw(const float* x, float* y, int64_t n, hipStream_t s);

@@ -325,7 +325,10 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     }
     for (const ConvInfo& c : p->finals) need = std::max(need, slab_need(B, T, c.cin, c.cout));
     for (const ConvInfo& c : p->mapping) need = std::max(need, slab_need(1, B, c.cin, c.cout));
-    if (p->c.cond_inputs > 0) need = std::max(need, slab_need(1, B, p->Cc, 2 * p->D));
+    if (p->c.cond_inputs > 0) {
+      need = std::max(need, slab_need(1, B, p->Cc, 2 * p->D));
+      need = std::max(need, wn_colsum_scratch_floats(B, 2 * p->D));
+    }
     L.slab_floats = need;
     L.slab = cv.take(need);
     L.bslab = 0; L.bsplits = 0;
@@ -598,7 +601,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
   if (g.defer) {
     // batched later; only the per-utterance column sums of g_u are needed now (conditioning)
     if (g.dcb) {
-      rc = wn_launch_colsum_per_batch(g.g_u, k.B, k.T, 2 * k.D, g.dcb, s);
+      rc = wn_launch_colsum_per_batch(g.g_u, k.B, k.T, 2 * k.D, g.dcb, g.slab, s);
       if (rc) return rc;
     }
   } else if (g_o) {
