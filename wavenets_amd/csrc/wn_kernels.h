@@ -128,6 +128,31 @@ int wn_launch_layer_fwd_f16(const WnLayerFwdArgs& a, hipStream_t s);
 size_t wn_frag16_floats(int I, int KK);
 int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- fused generation step (wn_gen.hip)
+struct WnGenBlock {
+  int64_t ring_off;      // workspace offset of this block's ring [nslots][B][R]
+  int64_t w16d_off;      // workspace offset of the fp16 split image of the gated conv
+  int64_t w16r_off;      // ... of conv1
+  int64_t bias_d_off;    // parameter offsets
+  int64_t bias_r_off;
+  int64_t cb_off;        // workspace offset of the [B][2D] conditioning bias, or < 0
+  int32_t nslots, dilation;
+};
+struct WnGenStepArgs {
+  const float* params;
+  float* ws;                       // workspace base (rings, images, row buffers)
+  const WnGenBlock* blocks;        // device table
+  const float* xin;                // [KS][B] raw sample ring
+  const float* causal_w;           // (KS, 1, R)
+  const float* causal_b;
+  int64_t zrow_off;                // [N][B][D] gated activations of this step
+  int64_t hrow_off;                // [B][R] last block output (use_skip False) or < 0
+  int64_t tau;
+  int32_t B, nblocks, residual;
+};
+int wn_gen_blocks_supported(int R, int D, int KS);
+int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, hipStream_t s);
+
 // ---------------------------------------------------------------- elementwise / loss / sampling
 int wn_launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
 int wn_launch_fill(float* p, float v, int64_t n, hipStream_t s);

@@ -78,7 +78,9 @@ struct wn_plan {
   WnTensorDesc* d_cov = nullptr;
   int njobs = 0, ncov = 0, jobs_B = 0, jobs_T = 0, jobs_splits = 0;
   bool jobs_drop = false;
-  bool jobs_skipk = false;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
+  bool jobs_skipk = false;
+  WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
+  int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   int prof_used = 0;
@@ -840,6 +842,7 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
+  if (p->d_gen) (void)hipFree(p->d_gen);
   delete p;
 }
 
@@ -1653,8 +1656,42 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
                      R.xin + (int64_t)(RF % p->KS) * B);
   const float* fragbase = pws + L.frag;
   float* Zrow = workspace + G.Zrow;
+  // fused step kernel (input conv + every block in one launch) when the split-precision block kernel
+  // is the one the sliding window uses; otherwise the blocks run as separate launches
+  const bool fused_step = p->fused16_ok && p->LPB == 1 && wn_debug_get(1) != 1 && wn_debug_get(6) != 1 &&
+                          wn_gen_blocks_supported(p->R, p->D, p->KS);
+  if (fused_step && (!p->d_gen || p->gen_B != B)) {
+    std::vector<WnGenBlock> tab(p->N);
+    for (int b = 0; b < p->N; ++b) {
+      const BlockInfo& bi = p->blocks[b];
+      WnGenBlock& g = tab[b];
+      g.ring_off = G.ring[b];
+      g.w16d_off = G.prime + L.frag + bi.dil.back().frag16;
+      g.w16r_off = G.prime + L.frag + bi.conv1.frag16;
+      g.bias_d_off = p->tensors[bi.dil.back().bias_t].off;
+      g.bias_r_off = p->tensors[bi.conv1.bias_t].off;
+      g.cb_off = p->c.cond_inputs > 0 ? G.prime + L.cb + (int64_t)b * B * 2 * p->D : -1;
+      g.nslots = G.nslots[b];
+      g.dilation = bi.dil.back().dil;
+    }
+    if (p->d_gen) { (void)hipFree(p->d_gen); p->d_gen = nullptr; }
+    WN_HIP_CHECK(hipMalloc((void**)&p->d_gen, tab.size() * sizeof(WnGenBlock)));
+    WN_HIP_CHECK(hipMemcpy(p->d_gen, tab.data(), tab.size() * sizeof(WnGenBlock), hipMemcpyHostToDevice));
+    p->gen_B = B;
+  }
   for (int step = 1; step < length; ++step) {
     const int64_t tau = (int64_t)RF + step - 1;        // time of the newest known sample
+    if (fused_step) {
+      WnGenStepArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.params = params; ga.ws = workspace; ga.blocks = p->d_gen; ga.xin = R.xin;
+      ga.causal_w = params + p->tensors[p->causal.kernel_t].off;
+      ga.causal_b = params + p->tensors[p->causal.bias_t].off;
+      ga.zrow_off = G.Zrow; ga.hrow_off = p->c.use_skip ? -1 : G.hrow0; ga.tau = tau;
+      ga.B = B; ga.nblocks = p->N; ga.residual = p->c.use_residual;
+      rc = wn_launch_gen_blocks(ga, p->R, p->KS, s);
+      if (rc) return rc;
+    } else {
     // input causal conv on [x[tau-(KS-1)], ..., x[tau]]  ->  block 0's ring slot tau
     {
       Gemm g(B, 1, p->R, ceil32(p->R));
@@ -1681,6 +1718,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
                                : (p->c.use_skip ? workspace + G.dummy : workspace + G.hrow0);
       rc = block_forward(k, f, s);
       if (rc) return rc;
+    }
     }
     const float* hin;
     if (p->c.use_skip) {
