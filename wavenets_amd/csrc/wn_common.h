@@ -40,8 +40,11 @@ __device__ __forceinline__ float wn_sigmoid(float x) { return 1.0f / (1.0f + exp
 __device__ __forceinline__ float wn_sigmoid_fast(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+// The fma is explicit on purpose: with -ffp-contract=fast the compiler may otherwise turn
+// (1 - 2r) * s into fma(-2r, s, s) in one kernel and into fma(-2, r, 1) * s in another, and the
+// generation kernels must reproduce the training-forward kernels bit for bit.
 __device__ __forceinline__ float wn_tanh_fast(float x) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+  return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)), 1.0f);
 }
 
 __device__ __forceinline__ float wn_act(float x, int act) {

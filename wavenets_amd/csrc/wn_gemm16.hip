@@ -134,7 +134,7 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
               *reinterpret_cast<f32x4*>(stage + tl * PITCH + 32 * jj + 8 * rq + 4 * h) = o;
             }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const int ncols = min(64, a.N - c0);         // multiple of 32
+          const int ncols = min(min(64, 32 * (JT - 2 * g2)), a.N - c0);   // multiple of 32; never past this block's tiles
           float* dst = a.y + row0 * a.ldy + (part ? a.N : 0) + c0;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -311,6 +311,120 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
 
     if (live) wn_g16_epilogue<JT, PITCH>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
   }
+  if (absmax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+  }
+}
+
+// Thin form for the few-row contractions of queued generation (rows = utterances, <= a few hundred):
+// the streamed kernel would run them in ONE chunk-synchronised workgroup.  Here every (32-row tile,
+// 32-column tile) pair is its own single-wave workgroup that walks the whole K range with the weight
+// fragments and the activations of the next PD k-steps in flight in a register ring.  The per-element
+// MFMA sequence (k order, lo*hi, hi*lo, hi*hi) is exactly the streamed kernel's, so the results are
+// bit-identical to what the sliding-window path computes for the same rows.
+template <int PD>
+__global__ __launch_bounds__(64) void wn_gemm_rows16_thin_kernel(WnGemmArgs a, const float* w16, int nks_total,
+                                                                 const float* absmax_in0, const float* absmax_in1,
+                                                                 float* absmax_out) {
+  constexpr int PITCH = 68;
+  __shared__ __attribute__((aligned(16))) float stage[32 * PITCH];
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & 31, h = lane >> 5;
+  float sc = 1.0f, inv_sc = 1.0f;
+  if (absmax_in0) {
+    float m = *absmax_in0;
+    if (absmax_in1) m = fmaxf(m, *absmax_in1);
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);
+      e = max(-100, min(100, e));
+      sc = ldexpf(1.0f, -e);
+      inv_sc = ldexpf(1.0f, e);
+    }
+  }
+  const int tiles_per_b = (a.T + 31) >> 5;
+  const int tile = blockIdx.x;
+  const int jb = blockIdx.y;
+  const int b = tile / tiles_per_b;
+  const int t0 = (tile % tiles_per_b) * 32;
+  const int t = t0 + tl;
+  const int rows_valid = min(32, a.T - t0);
+  const int64_t row0 = (int64_t)b * a.T + t0;
+
+  int ks_end[WN_MAXSEG];
+  {
+    int acc = 0;
+#pragma unroll
+    for (int s = 0; s < WN_MAXSEG; ++s) {
+      if (s < a.nseg) acc += (a.seg[s].K + 15) >> 4;
+      ks_end[s] = acc;
+    }
+  }
+  const float* xrow_s[WN_MAXSEG];
+  bool xok_s[WN_MAXSEG];
+  const int plane_ks0 = a.seg[0].plane_k > 0 ? a.seg[0].plane_k / 16 : 0;
+  const int64_t plane_st0 = a.seg[0].plane_stride;
+#pragma unroll
+  for (int s = 0; s < WN_MAXSEG; ++s) {
+    xrow_s[s] = nullptr;
+    xok_s[s] = false;
+    if (s < a.nseg) {
+      const int ts = t - a.seg[s].shift;
+      xok_s[s] = t < a.T && ts >= 0 && ts < a.T;
+      xrow_s[s] = a.seg[s].x + ((int64_t)b * a.T + (xok_s[s] ? ts : 0)) * a.seg[s].ldx + 4 * h;
+    }
+  }
+  auto load_x = [&](int ks, f32x4& q0, f32x4& q1) {
+    q0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    q1 = q0;
+    if (ks >= nks_total) return;
+    const float* xr = xrow_s[0];
+    bool ok = xok_s[0];
+    int kk = ks;
+#pragma unroll
+    for (int s = 1; s < WN_MAXSEG; ++s)
+      if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }
+    if (ok) {
+      if (plane_ks0 > 0 && ks < ks_end[0]) xr += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
+      q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
+      q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
+    }
+  };
+  // hi|lo fragments of (k-step, column tile jb); k-steps past the end are clamped (their activations are zero)
+  const h8* wbase = reinterpret_cast<const h8*>(w16) + lane;
+  auto load_w = [&](int ks, h8& hi, h8& lo) {
+    const int64_t blk = (int64_t)min(ks, nks_total - 1) * a.JTtot + jb;
+    hi = wbase[(blk * 2 + 0) * 64];
+    lo = wbase[(blk * 2 + 1) * 64];
+  };
+
+  f32x16 acc[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+  h8 wf[PD][2];
+  f32x4 xv[PD][2];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+    load_w(i, wf[i][0], wf[i][1]);
+    load_x(i, xv[i][0], xv[i][1]);
+  }
+  for (int ks0 = 0; ks0 < nks_total; ks0 += PD) {
+    wn_static_for<PD>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      h8 bh, bl;
+      wn_split8g(xv[i][0], xv[i][1], sc, bh, bl);
+      acc[0] = wn_mfma16g(wf[i][1], bh, acc[0]);
+      acc[0] = wn_mfma16g(wf[i][0], bl, acc[0]);
+      acc[0] = wn_mfma16g(wf[i][0], bh, acc[0]);
+      load_w(ks0 + i + PD, wf[i][0], wf[i][1]);
+      load_x(ks0 + i + PD, xv[i][0], xv[i][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  float wmax = 0.f;
+  wn_g16_epilogue<1, PITCH>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
   if (absmax_out) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
@@ -514,6 +628,13 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   int64_t gx = (tiles + 7) / 8;
   if (gx > 256) gx = 256;
   const int jt_need = (a.N + 31) / 32;
+  // few rows (queued generation): one wave per (row tile, column tile), see the thin kernel
+  if (tiles * jt_need <= 64 && tiles <= 8) {
+    hipLaunchKernelGGL(wn_gemm_rows16_thin_kernel<8>, dim3((unsigned)tiles, (unsigned)jt_need), dim3(64), 0, s, a, w16, nks,
+                       absmax_in0, absmax_in1, absmax_out);
+    WN_HIP_CHECK(hipGetLastError());
+    return WN_OK;
+  }
   // knob 2 = 1 disables the resident form
   if (jt_need == 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1 &&
       a.seg[0].plane_k == 0) {

@@ -2,13 +2,22 @@
 // Reference semantics: WaveNet.generate / _generation (src/model.py:241-307) with the per-layer queues
 // the reference left as a TODO (README.md:16, src/layers.py:226-290).
 //
-// Rows are utterances (lane & 31 = utterance, 32 per wave); a wave carries its utterances through the
-// whole block chain in registers: the output tile of block b is, unchanged, the current-tap B operand
-// of block b + 1 (wn_common.h), the older taps come from per-block ring buffers in HBM, the gated
-// activations z go to the row buffer that feeds the folded skip contraction.  The arithmetic is the
-// split-precision MFMA sequence of wn_layer16.hip in the same order, so every value is bit-identical to
-// what the sliding-window path computes for the same sample.  Weights (fp16 hi|lo images) stream from
-// L2: 2.4 MB per step at configs[1].
+// Rows are utterances (lane & 31 = utterance, 32 per wave).  Two launches per step:
+//
+//  wn_gen_pre_kernel    grid (utterance tiles, blocks).  Everything of a block's gated conv that does
+//                       NOT depend on this step's chain: u0_b = b_d (+ cb) + sum_{tap < k-1} W_tap^T x_b[tau - ..]
+//                       (the older taps sit in the block's ring buffer since earlier steps).  All blocks
+//                       in parallel; the accumulators go to a lane-major scratch image.
+//  wn_gen_chain_kernel  grid (utterance tiles).  One wave carries its utterances through the block chain
+//                       in registers: u = u0_b + W_{k-1}^T x_b[tau], gate, z row out, 1x1, residual; the
+//                       output tile of block b is, unchanged, the B operand of block b + 1 (wn_common.h).
+//                       While block b computes, the wave's own LDS-DMA brings block b + 1's weight
+//                       fragments and u0 image into the other half of LDS (no registers, no barrier:
+//                       a single wave only waits on its own vmcnt).
+//
+// The per-element MFMA sequence (bias, taps in k order, lo*hi, hi*lo, hi*hi) is the one of
+// wn_layer16.hip, merely cut between two launches, so every value is bit-identical to what the
+// sliding-window path computes for the same sample.
 #include <hip/hip_fp16.h>
 
 #include "wn_kernels.h"
@@ -26,187 +35,332 @@ __device__ __forceinline__ void gn_split8(const f32x4& q0, const f32x4& q1, gn_h
 }
 
 template <int R32, int D32, int KS>
-__global__ __launch_bounds__(64) void wn_gen_blocks_kernel(WnGenStepArgs a) {
-  constexpr int R = 32 * R32, D = 32 * D32, JU = 2 * D32, QR = R / 8;
-  constexpr int KS1 = KS * R / 16, KS2 = D / 16;
+struct GnShape {
+  static constexpr int R = 32 * R32, D = 32 * D32, JU = 2 * D32, QR = R / 8;
+  static constexpr int KSR = R / 16;                  // k-steps per tap
+  static constexpr int KS0 = (KS - 1) * KSR;          // k-steps of the older taps (pre kernel)
+  static constexpr int KS2 = D / 16;
+  static constexpr int WD_BYTES = KSR * JU * 2048;    // newest tap's hi|lo fragments
+  static constexpr int WR_BYTES = KS2 * R32 * 2048;   // conv1
+  static constexpr int U0_BYTES = JU * 4096;          // JU tiles x 16 accumulators x 64 lanes x 4 B
+  static constexpr int BUF_BYTES = WD_BYTES + WR_BYTES + U0_BYTES;
+};
+
+template <int R32, int D32, int KS>
+__global__ __launch_bounds__(64) void wn_gen_pre_kernel(WnGenStepArgs a) {
+  using S = GnShape<R32, D32, KS>;
+  constexpr int R = S::R, D = S::D, JU = S::JU, QR = S::QR, KSR = S::KSR, KS0 = S::KS0;
   const int lane = threadIdx.x & 63;
   const int tl = lane & 31, h = lane >> 5;
-  const int utt = blockIdx.x * 32 + tl;
-  const bool live = utt < a.B;
-  const int ur = live ? utt : 0;                     // clamped row for loads
-
-  // ---- input causal conv (C_in = 1): the k-ordered fma chain of the fp32 MFMA path, then + bias ----
-  f32x16 xc[R32];
-  {
-    float xs[KS];
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const int utt = tile * 32 + tl;
+  const int ur = utt < a.B ? utt : 0;
+  const WnGenBlock blk = a.blocks[b];
+  // weight fragments of the older taps: all requested at once (one L2 round trip)
+  const gn_h8* wd = reinterpret_cast<const gn_h8*>(a.ws + blk.w16d_off) + lane;
+  gn_h8 wf[KS0][JU][2];
 #pragma unroll
-    for (int t = 0; t < KS; ++t) xs[t] = a.xin[(int64_t)((a.tau - (KS - 1 - t)) % KS) * a.B + ur];
+  for (int ks = 0; ks < KS0; ++ks)
 #pragma unroll
-    for (int j = 0; j < R32; ++j)
+    for (int j = 0; j < JU; ++j) {
+      wf[ks][j][0] = wd[((ks * JU + j) * 2 + 0) * 64];
+      wf[ks][j][1] = wd[((ks * JU + j) * 2 + 1) * 64];
+    }
+  const float* ring = a.ws + blk.ring_off;
+  f32x4 xq[KS - 1][QR];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = 32 * j + wn_drow(r, h);
-        float acc = 0.f;
+  for (int t = 0; t + 1 < KS; ++t) {
+    const int64_t slot = (a.tau - (int64_t)(KS - 1 - t) * blk.dilation) % blk.nslots;
+    const float* src = ring + (slot * a.B + ur) * R + 4 * h;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) acc = fmaf(a.causal_w[t * R + c], xs[t], acc);
-        xc[j][r] = acc + a.causal_b[c];
-      }
+    for (int q = 0; q < QR; ++q) xq[t][q] = *reinterpret_cast<const f32x4*>(src + 8 * q);
   }
-
-  for (int b = 0; b < a.nblocks; ++b) {
-    const WnGenBlock blk = a.blocks[b];
-    float* ring = a.ws + blk.ring_off;
-    // ---- this block's input at time tau goes into its ring (read again d, 2d, ... steps later) ----
-    if (live) {
-      float* dst = ring + ((int64_t)(a.tau % blk.nslots) * a.B + utt) * R;
+  f32x16 u[JU];
+  const float* bias_d = a.params + blk.bias_d_off;
 #pragma unroll
-      for (int j = 0; j < R32; ++j)
+  for (int j = 0; j < JU; ++j)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          f32x4 o;
-          o.x = xc[j][4 * rq + 0]; o.y = xc[j][4 * rq + 1]; o.z = xc[j][4 * rq + 2]; o.w = xc[j][4 * rq + 3];
-          *reinterpret_cast<f32x4*>(dst + 32 * j + 8 * rq + 4 * h) = o;
-        }
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_d + 32 * j + 8 * rq + 4 * h);
+      u[j][4 * rq + 0] = bv.x; u[j][4 * rq + 1] = bv.y; u[j][4 * rq + 2] = bv.z; u[j][4 * rq + 3] = bv.w;
     }
-    // ---- taps: older ones from the ring, the newest from registers ----
-    f32x4 xq[KS][QR];
-#pragma unroll
-    for (int t = 0; t + 1 < KS; ++t) {
-      const int64_t slot = (a.tau - (int64_t)(KS - 1 - t) * blk.dilation) % blk.nslots;
-      const float* src = ring + (slot * a.B + ur) * R + 4 * h;
-#pragma unroll
-      for (int q = 0; q < QR; ++q) xq[t][q] = *reinterpret_cast<const f32x4*>(src + 8 * q);
-    }
-#pragma unroll
-    for (int q = 0; q < QR; ++q) {
-      const int j = q / 4, rq = q % 4;
-      xq[KS - 1][q] = f32x4{xc[j][4 * rq + 0], xc[j][4 * rq + 1], xc[j][4 * rq + 2], xc[j][4 * rq + 3]};
-    }
-    // ---- u = b_d (+ cb) + sum_tap W_tap^T x_tap ----
-    f32x16 u[JU];
-    const float* bias_d = a.params + blk.bias_d_off;
+  if (blk.cb_off >= 0) {
+    const float* cbp = a.ws + blk.cb_off + (int64_t)ur * 2 * D + 4 * h;
 #pragma unroll
     for (int j = 0; j < JU; ++j)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_d + 32 * j + 8 * rq + 4 * h);
-        u[j][4 * rq + 0] = bv.x; u[j][4 * rq + 1] = bv.y; u[j][4 * rq + 2] = bv.z; u[j][4 * rq + 3] = bv.w;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(cbp + 32 * j + 8 * rq);
+        u[j][4 * rq + 0] += cv.x; u[j][4 * rq + 1] += cv.y; u[j][4 * rq + 2] += cv.z; u[j][4 * rq + 3] += cv.w;
       }
-    if (blk.cb_off >= 0) {
-      const float* cbp = a.ws + blk.cb_off + (int64_t)ur * 2 * D + 4 * h;
+  }
+  wn_static_for<KS0>([&](auto sc) {
+    constexpr int ks = decltype(sc)::value;
+    constexpr int tap = ks / KSR, kk = ks % KSR;
+    gn_h8 bh, bl;
+    gn_split8(xq[tap][2 * kk], xq[tap][2 * kk + 1], bh, bl);
 #pragma unroll
-      for (int j = 0; j < JU; ++j)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const f32x4 cv = *reinterpret_cast<const f32x4*>(cbp + 32 * j + 8 * rq);
-          u[j][4 * rq + 0] += cv.x; u[j][4 * rq + 1] += cv.y; u[j][4 * rq + 2] += cv.z; u[j][4 * rq + 3] += cv.w;
-        }
+    for (int j = 0; j < JU; ++j) {
+      u[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j][1], bh, u[j], 0, 0, 0);
+      u[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j][0], bl, u[j], 0, 0, 0);
+      u[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j][0], bh, u[j], 0, 0, 0);
     }
-    // a single wave per 32 utterances has nobody to hide L2 latency behind: the weight fragments of
-    // k-step ks + PD are requested before the MFMAs of k-step ks (register ring, schedule pinned)
-    const gn_h8* wd = reinterpret_cast<const gn_h8*>(a.ws + blk.w16d_off) + lane;
-    const gn_h8* wr = reinterpret_cast<const gn_h8*>(a.ws + blk.w16r_off) + lane;
-    constexpr int PD = 2;
-    gn_h8 wring[PD + 1][JU][2];
-    wn_static_for<PD>([&](auto sc) {
-      constexpr int ks = decltype(sc)::value;
-      if constexpr (ks < KS1) {
+  });
+  // lane-major image [b][tile][JU * 4 quads][64 lanes] of float4: contiguous KiB per quad (LDS-DMA friendly)
+  f32x4* dst = reinterpret_cast<f32x4*>(a.ws + a.u0_off) + ((int64_t)b * gridDim.x + tile) * (JU * 4) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < JU; ++j) {
-          wring[ks % (PD + 1)][j][0] = wd[((ks * JU + j) * 2 + 0) * 64];
-          wring[ks % (PD + 1)][j][1] = wd[((ks * JU + j) * 2 + 1) * 64];
+  for (int j = 0; j < JU; ++j)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      dst[(j * 4 + rq) * 64] = f32x4{u[j][4 * rq + 0], u[j][4 * rq + 1], u[j][4 * rq + 2], u[j][4 * rq + 3]};
+}
+
+// workgroup barrier that only drains this wave's LDS/SMEM traffic: __syncthreads() would also wait for
+// the global prefetches and LDS-DMA that are meant to stay in flight across phases
+#define GN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Chain kernel: one workgroup per 32 utterances, JU = 2 * D / 32 "chain" waves + up to 8 "skip" waves.
+//   phase A  chain wave w: u tile w = u0 + W_{k-1}^T x        (x as ready-made hi|lo B operands in LDS)
+//   phase B  chain wave w: gated activation of z k-step w  -> z row (HBM) and z hi|lo B operand (LDS)
+//   phase C  chain wave j < R / 32: o tile j = b_r + W_r^T z, x_next = o (+ x) -> next ring slot, x operands
+//            skip wave s: acc_s += W_{s,b}^T z   (the folded skip contraction, k order = block order)
+// Every wave brings the weight fragments of ITS tile for block b + 1 into its own corner of the other
+// LDS half by LDS-DMA while block b runs, so weights need neither registers nor cross-wave ordering.
+template <int R32, int D32, int KS>
+__global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenStepArgs a) {
+  using S = GnShape<R32, D32, KS>;
+  constexpr int R = S::R, D = S::D, JU = S::JU, KSR = S::KSR, KS0 = S::KS0, KS2 = S::KS2;
+  // one LDS half per block parity: [newest-tap fragments | conv1 fragments | u0 image (reused as the u
+  // exchange buffer once consumed) | conv1 bias, one 256 B copy per conv1 wave]
+  constexpr int U0_OFF = S::WD_BYTES + S::WR_BYTES, BR_OFF = U0_OFF + S::U0_BYTES;
+  constexpr int HALF = BR_OFF + R32 * 256;
+  constexpr int XOP_BYTES = KSR * 2048, ZOP_BYTES = KS2 * 2048;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HALF + XOP_BYTES + ZOP_BYTES];
+  unsigned char* const xop = smem + 2 * HALF;
+  unsigned char* const zop = xop + XOP_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;                  // wave-uniform roles
+  const int tl = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x;
+  const int utt = tile * 32 + tl;
+  const bool live = utt < a.B;
+  const int ur = live ? utt : 0;
+  const bool is_chain = wave < JU;
+  const bool is_conv1 = wave < R32;
+  const int sw = wave - JU;                           // skip tile of a skip wave
+  const int nblocks = a.nblocks;
+
+  // everything this wave needs of block b -> ITS corner of LDS half (b & 1), by LDS-DMA: no registers,
+  // and no cross-wave ordering because a wave only ever reads back what it requested itself
+  auto dma = [&](int b, const WnGenBlock& nb) {
+    unsigned char* buf = smem + (b & 1) * HALF;
+    const f32x4* wd = reinterpret_cast<const f32x4*>(a.ws + nb.w16d_off) + (int64_t)KS0 * JU * 128 + lane;
+#pragma unroll
+    for (int kk = 0; kk < KSR; ++kk)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        const int blk = (kk * JU + wave) * 2 + hl;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wd + blk * 64),
+                                         (__attribute__((address_space(3))) void*)(buf + blk * 1024), 16, 0, 0);
+      }
+    const f32x4* u0 = reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * gridDim.x + tile) * (JU * 4) + wave * 4) * 64 + lane;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(u0 + rq * 64),
+                                       (__attribute__((address_space(3))) void*)(buf + U0_OFF + (wave * 4 + rq) * 1024), 16, 0, 0);
+    if (is_conv1) {
+      const f32x4* wr = reinterpret_cast<const f32x4*>(a.ws + nb.w16r_off) + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const int blk = (ks * R32 + wave) * 2 + hl;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wr + blk * 64),
+                                           (__attribute__((address_space(3))) void*)(buf + S::WD_BYTES + blk * 1024), 16, 0, 0);
         }
-      }
-    });
-    // conv1 fragments (all of them: KS2 * R32 * 2 <= 16 vectors) are requested up front as well
-    gn_h8 rfr[KS2][R32][2];
-#pragma unroll
-    for (int ks = 0; ks < KS2; ++ks)
-#pragma unroll
-      for (int j = 0; j < R32; ++j) {
-        rfr[ks][j][0] = wr[((ks * R32 + j) * 2 + 0) * 64];
-        rfr[ks][j][1] = wr[((ks * R32 + j) * 2 + 1) * 64];
-      }
-    wn_static_for<KS1>([&](auto sc) {
-      constexpr int ks = decltype(sc)::value;
-      constexpr int tap = ks / (R / 16), kk = ks % (R / 16);
-      if constexpr (ks + PD < KS1) {
-#pragma unroll
-        for (int j = 0; j < JU; ++j) {
-          wring[(ks + PD) % (PD + 1)][j][0] = wd[(((ks + PD) * JU + j) * 2 + 0) * 64];
-          wring[(ks + PD) % (PD + 1)][j][1] = wd[(((ks + PD) * JU + j) * 2 + 1) * 64];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      gn_h8 bh, bl;
-      gn_split8(xq[tap][2 * kk], xq[tap][2 * kk + 1], bh, bl);
-#pragma unroll
-      for (int j = 0; j < JU; ++j) {
-        const gn_h8 ah = wring[ks % (PD + 1)][j][0];
-        const gn_h8 al = wring[ks % (PD + 1)][j][1];
-        u[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, u[j], 0, 0, 0);
-        u[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, u[j], 0, 0, 0);
-        u[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, u[j], 0, 0, 0);
-      }
-    });
-    // ---- gate, z row for the folded skip contraction ----
-#pragma unroll
-    for (int j = 0; j < D32; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) u[j][r] = wn_tanh_fast(u[j][r]) * wn_sigmoid_fast(u[j + D32][r]);
-    if (live) {
-      float* zdst = a.ws + a.zrow_off + ((int64_t)b * a.B + utt) * D;
-#pragma unroll
-      for (int j = 0; j < D32; ++j)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          f32x4 o;
-          o.x = u[j][4 * rq + 0]; o.y = u[j][4 * rq + 1]; o.z = u[j][4 * rq + 2]; o.w = u[j][4 * rq + 3];
-          *reinterpret_cast<f32x4*>(zdst + 32 * j + 8 * rq + 4 * h) = o;
-        }
+      const float* br = a.params + nb.bias_r_off + min(lane, R - 1);     // one dword per lane: 64 biases
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)br,
+                                       (__attribute__((address_space(3))) void*)(buf + BR_OFF + wave * 256), 4, 0, 0);
     }
-    // ---- o = b_r + W_r^T z ; x_next = o (+ x) ----
-    f32x16 o[R32];
-    const float* bias_r = a.params + blk.bias_r_off;
+  };
+  gn_h8 wsk[KS2][2];                                  // skip waves: fragments of the current block
+  auto pre_skip = [&](int b) {
+    const gn_h8* wsi = reinterpret_cast<const gn_h8*>(a.ws + a.skip_w16_off) + lane;
 #pragma unroll
-    for (int j = 0; j < R32; ++j)
+    for (int ks = 0; ks < KS2; ++ks) {
+      const int64_t blk = ((int64_t)(b * KS2 + ks) * a.skip_tiles + sw) * 2;
+      wsk[ks][0] = wsi[(blk + 0) * 64];
+      wsk[ks][1] = wsi[(blk + 1) * 64];
+    }
+  };
+  // tile of fp32 values (this lane's 16 accumulators = two k-steps) -> hi|lo B operands of k-steps 2j, 2j+1
+  auto put_xop = [&](const f32x16& x, int j) {
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_r + 32 * j + 8 * rq + 4 * h);
-        o[j][4 * rq + 0] = bv.x; o[j][4 * rq + 1] = bv.y; o[j][4 * rq + 2] = bv.z; o[j][4 * rq + 3] = bv.w;
-      }
-    wn_static_for<KS2>([&](auto sc) {
-      constexpr int ks = decltype(sc)::value;
-      constexpr int jz = ks / 2, r0 = 8 * (ks % 2);
-      const f32x4 q0 = {u[jz][r0 + 0], u[jz][r0 + 1], u[jz][r0 + 2], u[jz][r0 + 3]};
-      const f32x4 q1 = {u[jz][r0 + 4], u[jz][r0 + 5], u[jz][r0 + 6], u[jz][r0 + 7]};
+    for (int hf = 0; hf < 2; ++hf) {
+      const f32x4 q0 = {x[8 * hf + 0], x[8 * hf + 1], x[8 * hf + 2], x[8 * hf + 3]};
+      const f32x4 q1 = {x[8 * hf + 4], x[8 * hf + 5], x[8 * hf + 6], x[8 * hf + 7]};
       gn_h8 bh, bl;
       gn_split8(q0, q1, bh, bl);
+      gn_h8* dst = reinterpret_cast<gn_h8*>(xop + (2 * j + hf) * 2048) + lane;
+      dst[0] = bh;
+      dst[64] = bl;
+    }
+  };
+
+  WnGenBlock cur = a.blocks[0];
+  WnGenBlock nxt = a.blocks[min(1, nblocks - 1)];
+  // `carry`: conv1 waves = the block input / output tile x; skip waves = the skip accumulator tile
+  f32x16 carry;
 #pragma unroll
-      for (int j = 0; j < R32; ++j) {
-        const gn_h8 ah = rfr[ks][j][0];
-        const gn_h8 al = rfr[ks][j][1];
-        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, o[j], 0, 0, 0);
-        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, o[j], 0, 0, 0);
-        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, o[j], 0, 0, 0);
-      }
-    });
+  for (int r = 0; r < 16; ++r) carry[r] = 0.f;
+  if (is_chain) dma(0, cur);
+  else pre_skip(0);
+
+  // ---- input causal conv (C_in = 1): the k-ordered fma chain of the fp32 MFMA path, then + bias ----
+  if (is_conv1) {
+    float xs[KS];
 #pragma unroll
-    for (int j = 0; j < R32; ++j)
+    for (int t = 0; t < KS; ++t) xs[t] = a.xin[(int64_t)((a.tau - (KS - 1 - t)) % KS) * a.B + ur];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xc[j][r] = a.residual ? o[j][r] + xc[j][r] : o[j][r];
+    for (int r = 0; r < 16; ++r) {
+      const int c = 32 * wave + wn_drow(r, h);
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < KS; ++t) acc = fmaf(a.causal_w[t * R + c], xs[t], acc);
+      carry[r] = acc + a.causal_b[c];
+    }
+    put_xop(carry, wave);
   }
-  // ---- the last block output feeds the head when use_skip is False ----
-  if (a.hrow_off >= 0 && live) {
-    float* dst = a.ws + a.hrow_off + (int64_t)utt * R;
+  f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;           // gated activations of the previous block (stored late)
+  GN_BARRIER();
+
+  for (int b = 0; b < nblocks; ++b) {
+    const WnGenBlock nn = a.blocks[min(b + 2, nblocks - 1)];
+    unsigned char* const half = smem + (b & 1) * HALF;
+    if (is_chain) {
+      // everything requested at the top of the previous block (block b's fragments, u0, bias; the
+      // stores) is complete.  All of this wave's global traffic is issued HERE, one block before it
+      // is needed, so this wait never sees a fresh request.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (live) {
+        if (b > 0) {
+          float* zdst = a.ws + a.zrow_off + ((int64_t)(b - 1) * a.B + utt) * D + 16 * wave + 4 * h;
+          *reinterpret_cast<f32x4*>(zdst) = z0;
+          *reinterpret_cast<f32x4*>(zdst + 8) = z1;
+        }
+        if (is_conv1) {                               // this block's input at time tau -> its ring
+          float* dst = a.ws + cur.ring_off + ((int64_t)(a.tau % cur.nslots) * a.B + utt) * R + 32 * wave + 4 * h;
 #pragma unroll
-    for (int j = 0; j < R32; ++j)
+          for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{carry[4 * rq + 0], carry[4 * rq + 1], carry[4 * rq + 2], carry[4 * rq + 3]};
+        }
+      }
+      if (b + 1 < nblocks) dma(b + 1, nxt);
+      asm volatile("" ::: "memory");
+      // ---- phase A: u tile `wave` = u0 + W_{k-1}^T x ----
+      f32x16 u;
+      f32x4* ub = reinterpret_cast<f32x4*>(half + U0_OFF) + (wave * 4) * 64 + lane;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        f32x4 o;
-        o.x = xc[j][4 * rq + 0]; o.y = xc[j][4 * rq + 1]; o.z = xc[j][4 * rq + 2]; o.w = xc[j][4 * rq + 3];
-        *reinterpret_cast<f32x4*>(dst + 32 * j + 8 * rq + 4 * h) = o;
+        const f32x4 v = ub[rq * 64];
+        u[4 * rq + 0] = v.x; u[4 * rq + 1] = v.y; u[4 * rq + 2] = v.z; u[4 * rq + 3] = v.w;
       }
+      const gn_h8* wl = reinterpret_cast<const gn_h8*>(half) + wave * 128 + lane;
+      const gn_h8* xl = reinterpret_cast<const gn_h8*>(xop) + lane;
+      wn_static_for<KSR>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        const gn_h8 ah = wl[((kk * JU) * 2 + 0) * 64];
+        const gn_h8 al = wl[((kk * JU) * 2 + 1) * 64];
+        const gn_h8 bh = xl[(kk * 2 + 0) * 64];
+        const gn_h8 bl = xl[(kk * 2 + 1) * 64];
+        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, u, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, u, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, u, 0, 0, 0);
+      });
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
+    }
+    GN_BARRIER();                                     // (1) u tiles visible
+    if (is_chain) {
+      // ---- phase B: z k-step `wave` = channels 16 * wave + {4h.., 8 + 4h..} ----
+      const int jz = wave >> 1, rq0 = 2 * (wave & 1);
+      const f32x4* uf = reinterpret_cast<const f32x4*>(half + U0_OFF) + (jz * 4 + rq0) * 64 + lane;
+      const f32x4* ug = reinterpret_cast<const f32x4*>(half + U0_OFF) + ((jz + D32) * 4 + rq0) * 64 + lane;
+      const f32x4 f0 = uf[0], f1 = uf[64], g0 = ug[0], g1 = ug[64];
+      z0.x = wn_tanh_fast(f0.x) * wn_sigmoid_fast(g0.x); z0.y = wn_tanh_fast(f0.y) * wn_sigmoid_fast(g0.y);
+      z0.z = wn_tanh_fast(f0.z) * wn_sigmoid_fast(g0.z); z0.w = wn_tanh_fast(f0.w) * wn_sigmoid_fast(g0.w);
+      z1.x = wn_tanh_fast(f1.x) * wn_sigmoid_fast(g1.x); z1.y = wn_tanh_fast(f1.y) * wn_sigmoid_fast(g1.y);
+      z1.z = wn_tanh_fast(f1.z) * wn_sigmoid_fast(g1.z); z1.w = wn_tanh_fast(f1.w) * wn_sigmoid_fast(g1.w);
+      gn_h8 bh, bl;
+      gn_split8(z0, z1, bh, bl);
+      gn_h8* zd = reinterpret_cast<gn_h8*>(zop + wave * 2048) + lane;
+      zd[0] = bh;
+      zd[64] = bl;
+    }
+    GN_BARRIER();                                     // (2) z operands visible
+    if (is_conv1) {
+      // ---- phase C: o tile `wave` = b_r + W_r^T z, x_next = o (+ x) ----
+      f32x16 o;
+      const float* bl_ = reinterpret_cast<const float*>(half + BR_OFF + wave * 256) + 32 * wave + 4 * h;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bl_ + 8 * rq);
+        o[4 * rq + 0] = v.x; o[4 * rq + 1] = v.y; o[4 * rq + 2] = v.z; o[4 * rq + 3] = v.w;
+      }
+      const gn_h8* wl = reinterpret_cast<const gn_h8*>(half + S::WD_BYTES) + wave * 128 + lane;
+      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
+      wn_static_for<KS2>([&](auto kc) {
+        constexpr int ks = decltype(kc)::value;
+        const gn_h8 ah = wl[((ks * R32) * 2 + 0) * 64];
+        const gn_h8 al = wl[((ks * R32) * 2 + 1) * 64];
+        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
+        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, o, 0, 0, 0);
+      });
+#pragma unroll
+      for (int r = 0; r < 16; ++r) carry[r] = a.residual ? o[r] + carry[r] : o[r];
+      if (b + 1 < nblocks) put_xop(carry, wave);
+    } else if (!is_chain) {
+      // ---- skip wave: acc += W_{s,b}^T z ----
+      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
+        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
+        carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][1], bh, carry, 0, 0, 0);
+        carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bl, carry, 0, 0, 0);
+        carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bh, carry, 0, 0, 0);
+      }
+      if (b + 1 < nblocks) pre_skip(b + 1);
+    }
+    cur = nxt;
+    nxt = nn;
+    GN_BARRIER();                                     // (3) x operands visible, z operands free
+  }
+  if (is_chain && live) {                             // gated activations of the last block
+    float* zdst = a.ws + a.zrow_off + ((int64_t)(nblocks - 1) * a.B + utt) * D + 16 * wave + 4 * h;
+    *reinterpret_cast<f32x4*>(zdst) = z0;
+    *reinterpret_cast<f32x4*>(zdst + 8) = z1;
+  }
+  // ---- the last block output feeds the head when use_skip is False ----
+  if (a.hrow_off >= 0 && live && is_conv1) {
+    float* dst = a.ws + a.hrow_off + (int64_t)utt * R + 32 * wave + 4 * h;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{carry[4 * rq + 0], carry[4 * rq + 1], carry[4 * rq + 2], carry[4 * rq + 3]};
+  }
+  // ---- folded skip sum + summed biases (the epilogue of the rows contraction it replaces) ----
+  if (!is_chain && live) {
+    const float* bs = a.ws + a.skip_bias_off + 32 * sw + 4 * h;
+    float* dst = a.ws + a.skiprow_off + (int64_t)utt * a.skip_ld + 32 * sw + 4 * h;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + 8 * rq);
+      *reinterpret_cast<f32x4*>(dst + 8 * rq) =
+          f32x4{carry[4 * rq + 0] + bv.x, carry[4 * rq + 1] + bv.y, carry[4 * rq + 2] + bv.z, carry[4 * rq + 3] + bv.w};
+    }
   }
 }
 
@@ -216,11 +370,24 @@ int wn_gen_blocks_supported(int R, int D, int KS) {
   return 0;
 }
 
-int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, hipStream_t s) {
+// the chain kernel can carry the folded skip contraction when its output is at most 8 column tiles
+int wn_gen_skip_fusable(int S) { return S % 32 == 0 && S / 32 >= 1 && S / 32 <= 8; }
+
+int64_t wn_gen_u0_floats(int B, int nblocks, int D) {
+  return (int64_t)nblocks * ((B + 31) / 32) * (2 * D / 32) * 1024;
+}
+
+template <int R32, int D32, int KS>
+static void gn_launch(const WnGenStepArgs& a, hipStream_t s) {
   const unsigned gx = (unsigned)((a.B + 31) / 32);
-  if (R == 32 && KS == 2) hipLaunchKernelGGL((wn_gen_blocks_kernel<1, 1, 2>), dim3(gx), dim3(64), 0, s, a);
-  else if (R == 32 && KS == 3) hipLaunchKernelGGL((wn_gen_blocks_kernel<1, 1, 3>), dim3(gx), dim3(64), 0, s, a);
-  else if (R == 64 && KS == 2) hipLaunchKernelGGL((wn_gen_blocks_kernel<2, 2, 2>), dim3(gx), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((wn_gen_pre_kernel<R32, D32, KS>), dim3(gx, (unsigned)a.nblocks), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((wn_gen_chain_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + a.skip_tiles)), 0, s, a);
+}
+
+int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, hipStream_t s) {
+  if (R == 32 && KS == 2) gn_launch<1, 1, 2>(a, s);
+  else if (R == 32 && KS == 3) gn_launch<1, 1, 3>(a, s);
+  else if (R == 64 && KS == 2) gn_launch<2, 2, 2>(a, s);
   else { wn_set_error("gen_blocks: unsupported shape"); return WN_E_UNSUPPORTED; }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;

@@ -147,10 +147,17 @@ struct WnGenStepArgs {
   const float* causal_b;
   int64_t zrow_off;                // [N][B][D] gated activations of this step
   int64_t hrow_off;                // [B][R] last block output (use_skip False) or < 0
+  int64_t skip_w16_off;            // fp16 split image of the folded skip contraction (skip_tiles > 0)
+  int64_t skip_bias_off;           // summed skip biases
+  int64_t skiprow_off;             // [B][skip_ld] folded skip sum of this step
+  int32_t skip_tiles, skip_ld;     // skip waves (column tiles of 32) carried by the chain kernel, or 0
+  int64_t u0_off;                  // [N][tiles][2D/32 * 1024] partial gated-conv accumulators (pre kernel -> chain)
   int64_t tau;
   int32_t B, nblocks, residual;
 };
 int wn_gen_blocks_supported(int R, int D, int KS);
+int64_t wn_gen_u0_floats(int B, int nblocks, int D);
+int wn_gen_skip_fusable(int S);
 int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise / loss / sampling

@@ -1541,6 +1541,7 @@ struct GenLayout {
   std::vector<int64_t> ring;           // per block [nslots][B][R]
   std::vector<int> nslots;
   int64_t Zrow, skiprow, hrow0, hrow1, dummy;   // per-step rows
+  int64_t u0;                          // fused step: partial accumulators of all blocks
   std::vector<int64_t> HArow;
   int64_t total;
 };
@@ -1555,7 +1556,7 @@ GenLayout gen_layout(const wn_plan* p, int B, bool queued) {
   G.last = cv.take((int64_t)B * p->Cout);
   G.lastp = cv.take((int64_t)B * p->Cout);
   G.samp = cv.take(B);
-  G.xin = G.Zrow = G.skiprow = G.hrow0 = G.hrow1 = G.dummy = 0;
+  G.xin = G.Zrow = G.skiprow = G.hrow0 = G.hrow1 = G.dummy = G.u0 = 0;
   if (queued) {
     G.xin = cv.take((int64_t)p->KS * B);
     for (int b = 0; b < p->N; ++b) {
@@ -1568,6 +1569,7 @@ GenLayout gen_layout(const wn_plan* p, int B, bool queued) {
     G.hrow0 = cv.take((int64_t)B * p->R);
     G.hrow1 = cv.take((int64_t)B * 2 * p->D);
     G.dummy = cv.take((int64_t)B * p->R);
+    G.u0 = cv.take(wn_gen_u0_floats(B, p->N, p->D));
     for (size_t i = 0; i + 1 < p->finals.size(); ++i) G.HArow.push_back(cv.take((int64_t)B * p->finals[i].cout));
   }
   G.total = cv.pos;
@@ -1614,6 +1616,12 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   hipStream_t s = (hipStream_t)stream;
   const int RF = wn_plan_receptive_field(p);
   const GenLayout G = gen_layout(p, B, queued != 0);
+  if (wn_debug_get(7) == 1) {                         // knob 7 = 1: print the generation workspace map
+    fprintf(stderr, "gen layout: prime=%lld win0=%lld last=%lld xin=%lld Zrow=%lld skiprow=%lld hrow0=%lld hrow1=%lld dummy=%lld u0=%lld total=%lld\n",
+            (long long)G.prime, (long long)G.win0, (long long)G.last, (long long)G.xin, (long long)G.Zrow, (long long)G.skiprow,
+            (long long)G.hrow0, (long long)G.hrow1, (long long)G.dummy, (long long)G.u0, (long long)G.total);
+    for (size_t b = 0; b < G.ring.size(); ++b) fprintf(stderr, "  ring[%zu]=%lld nslots=%d\n", b, (long long)G.ring[b], G.nslots[b]);
+  }
   if (ws_floats < G.total) { wn_set_error("generate: workspace too small"); return WN_E_INVALID; }
   if (length == 0) return WN_OK;
   float* pws = workspace + G.prime;
@@ -1660,6 +1668,8 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   // is the one the sliding window uses; otherwise the blocks run as separate launches
   const bool fused_step = p->fused16_ok && p->LPB == 1 && wn_debug_get(1) != 1 && wn_debug_get(6) != 1 &&
                           wn_gen_blocks_supported(p->R, p->D, p->KS);
+  const bool skip_in_chain = fused_step && p->c.use_skip && p->frag16_skipF >= 0 && wn_gen_skip_fusable(p->Sh) &&
+                             wn_debug_get(6) != 2;   // knob 6 = 2: skip contraction as its own launch
   if (fused_step && (!p->d_gen || p->gen_B != B)) {
     std::vector<WnGenBlock> tab(p->N);
     for (int b = 0; b < p->N; ++b) {
@@ -1687,6 +1697,12 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       ga.params = params; ga.ws = workspace; ga.blocks = p->d_gen; ga.xin = R.xin;
       ga.causal_w = params + p->tensors[p->causal.kernel_t].off;
       ga.causal_b = params + p->tensors[p->causal.bias_t].off;
+      ga.u0_off = G.u0;
+      if (skip_in_chain) {
+        ga.skip_w16_off = G.prime + L.frag + p->frag16_skipF;
+        ga.skip_bias_off = G.prime + L.bias_sum;
+        ga.skiprow_off = G.skiprow; ga.skip_ld = p->Sh; ga.skip_tiles = p->Sh / 32;
+      }
       ga.zrow_off = G.Zrow; ga.hrow_off = p->c.use_skip ? -1 : G.hrow0; ga.tau = tau;
       ga.B = B; ga.nblocks = p->N; ga.residual = p->c.use_residual;
       rc = wn_launch_gen_blocks(ga, p->R, p->KS, s);
@@ -1721,8 +1737,11 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     }
     }
     const float* hin;
-    if (p->c.use_skip) {
-      rc = Gemm(B, 1, p->Sh, ceil32(p->Sh)).seg_planes(Zrow, p->Dp, (int64_t)B * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
+    if (skip_in_chain) {
+      hin = workspace + G.skiprow;
+    } else if (p->c.use_skip) {
+      // utterances are the ROWS of these contractions (no time shift, no per-utterance bias here)
+      rc = Gemm(1, B, p->Sh, ceil32(p->Sh)).seg_planes(Zrow, p->Dp, (int64_t)B * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
                .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
                .bias(pws + L.bias_sum).run(workspace + G.skiprow, p->Sh, s);
       if (rc) return rc;
@@ -1735,7 +1754,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       const ConvInfo& c = p->finals[i];
       const bool lastl = (i + 1 == p->finals.size());
       float* dst = lastl ? last : workspace + G.HArow[i];
-      rc = Gemm(B, 1, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
+      rc = Gemm(1, B, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
                .w16(c.frag16 >= 0 ? fragbase + c.frag16 : nullptr)
                .bias(params + p->tensors[c.bias_t].off).act(lastl ? WN_ACT_LINEAR : p->c.activation).run(dst, c.cout, s);
       if (rc) return rc;
