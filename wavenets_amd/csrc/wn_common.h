@@ -109,6 +109,13 @@ __device__ __forceinline__ void wn_gate_bwd(float dz, float g, float z, float& d
   dug = dz * z * (1.f - g);
 }
 
+// the two halves separately (same arithmetic as wn_gate_bwd)
+__device__ __forceinline__ float wn_gate_bwd_f(float dz, float g, float z) {
+  const float a = g > 1e-30f ? z / g : 0.f;
+  return dz * g * (1.f - a * a);
+}
+__device__ __forceinline__ float wn_gate_bwd_g(float dz, float g, float z) { return dz * z * (1.f - g); }
+
 // running max-abs of a tensor (non-negative floats order like their bit patterns); the plain read
 // first keeps almost every wave off the atomic (one address: contention would serialise them)
 __device__ __forceinline__ void wn_absmax_publish(float* slot, float v) {

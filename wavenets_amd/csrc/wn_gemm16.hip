@@ -22,12 +22,14 @@ __device__ __forceinline__ f32x16 wn_mfma16g(h8 a, h8 b, f32x16 c) {
 }
 
 __device__ __forceinline__ void wn_split8g(const f32x4& q0, const f32x4& q1, float s, h8& hi, h8& lo) {
-  const float v[8] = {q0.x * s, q0.y * s, q0.z * s, q0.w * s, q1.x * s, q1.y * s, q1.z * s, q1.w * s};
+  // hi = fp16(q * s); lo = fp16(q * s - hi) with the product unrounded (explicit fma: one operation
+  // fewer in a loop that is VALU-bound on this split, and independent of the contraction mode)
+  const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const _Float16 h = (_Float16)v[e];
+    const _Float16 h = (_Float16)(v[e] * s);
     hi[e] = h;
-    lo[e] = (_Float16)(v[e] - (float)h);
+    lo[e] = (_Float16)__builtin_fmaf(v[e], s, -(float)h);
   }
 }
 
@@ -110,11 +112,14 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
                   gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
                   zv = *reinterpret_cast<const f32x4*>(a.aux2 + row * a.ld_aux2 + n0);
                 }
-                float duf, dug;
-                wn_gate_bwd(v[0], gv.x, zv.x, duf, dug); v[0] = part == 0 ? duf : dug;
-                wn_gate_bwd(v[1], gv.y, zv.y, duf, dug); v[1] = part == 0 ? duf : dug;
-                wn_gate_bwd(v[2], gv.z, zv.z, duf, dug); v[2] = part == 0 ? duf : dug;
-                wn_gate_bwd(v[3], gv.w, zv.w, duf, dug); v[3] = part == 0 ? duf : dug;
+                // each pass evaluates only the derivative it stores (filter half, then gate half)
+                if (part == 0) {
+                  v[0] = wn_gate_bwd_f(v[0], gv.x, zv.x); v[1] = wn_gate_bwd_f(v[1], gv.y, zv.y);
+                  v[2] = wn_gate_bwd_f(v[2], gv.z, zv.z); v[3] = wn_gate_bwd_f(v[3], gv.w, zv.w);
+                } else {
+                  v[0] = wn_gate_bwd_g(v[0], gv.x, zv.x); v[1] = wn_gate_bwd_g(v[1], gv.y, zv.y);
+                  v[2] = wn_gate_bwd_g(v[2], gv.z, zv.z); v[3] = wn_gate_bwd_g(v[3], gv.w, zv.w);
+                }
               }
               wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             }

@@ -83,10 +83,9 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_skip_kernel(WnWgSkipArgs a) {
   auto split8 = [&](const float (&v)[8], float s, ws_h8& hi, ws_h8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float x = v[e] * s;
-      const _Float16 hh = (_Float16)x;
+      const _Float16 hh = (_Float16)(v[e] * s);
       hi[e] = hh;
-      lo[e] = (_Float16)(x - (float)hh);
+      lo[e] = (_Float16)__builtin_fmaf(v[e], s, -(float)hh);     // product unrounded (explicit fma)
     }
   };
 
