@@ -483,6 +483,7 @@ struct BlockBufs {
   float* x_out;             // [rows][R]
   const float* xt[3];       // queued generation: per-tap input rows (no time shift), or null
   const float* res;         // residual source when it is not x (dropout: x is the dropped copy), or null
+  bool pre_done;            // queued generation: the non-gated convs already ran, xt[] are the gated conv's taps
 };
 
 int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
@@ -490,7 +491,8 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
   const float* h = f.x;
   int hc = k.Cin;
   int rc;
-  for (int i = 0; i + 1 < k.depth; ++i) {
+  if (f.pre_done && k.depth > 1) { h = nullptr; hc = k.D; }
+  for (int i = 0; i + 1 < k.depth && !f.pre_done; ++i) {
     Gemm g(k.B, k.T, k.D, ceil32(k.D));
     for (int t = 0; t < k.KS; ++t) g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[i], k.Fd[i] + t * k.Fd_stride[i]);
     rc = g.bias(k.bd[i]).act(k.act).run(f.P[i], k.D, s);
@@ -952,8 +954,11 @@ struct FwdCtx {
 // queued generation state: per block a ring of its most recent input rows, [slot][B][R]
 struct GenRings {
   float* xin;                  // [KS][B] raw samples
-  std::vector<float*> h;       // per block: [nslots_b][B][R]
+  std::vector<float*> h;       // per block: [nslots_b][B][R] inputs of the block's first dilated conv
   std::vector<int> nslots;
+  // layers_per_block > 1: hp[b][i] = [nslots_p[b][i]][B][D] inputs of dilated conv i + 1 (= outputs of conv i)
+  std::vector<std::vector<float*>> hp;
+  std::vector<std::vector<int>> nslots_p;
 };
 
 __global__ void wn_ring_capture_kernel(const float* src, int B, int T, int C, int nslots, float* ring) {
@@ -1064,6 +1069,11 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
       rc = ring_capture(f.x_out, B, T, p->R, rings->nslots[b + 1], rings->h[b + 1], s);
       if (rc) return rc;
     }
+    if (rings)
+      for (int i = 0; i + 1 < p->LPB; ++i) {
+        rc = ring_capture(f.P[i], B, T, p->D, rings->nslots_p[b][i], rings->hp[b][i], s);
+        if (rc) return rc;
+      }
   }
   // skip sum folded into one contraction over all blocks' gated activations (src/model.py:235-236
   // with src/layers.py:216-219), or the last block output when use_skip is False
@@ -1538,8 +1548,10 @@ struct GenLayout {
   int64_t prime;                       // priming forward workspace (make_layout(B, RF, inference))
   int64_t win0, win1, last, lastp, samp;
   int64_t xin;                         // [KS][B]
-  std::vector<int64_t> ring;           // per block [nslots][B][R]
+  std::vector<int64_t> ring;           // per block [nslots][B][R]: inputs of the first dilated conv
   std::vector<int> nslots;
+  std::vector<std::vector<int64_t>> ringp;   // layers_per_block > 1: inputs of dilated conv i + 1, [nslots][B][D]
+  std::vector<std::vector<int>> nslots_p;
   int64_t Zrow, skiprow, hrow0, hrow1, dummy;   // per-step rows
   int64_t u0;                          // fused step: partial accumulators of all blocks
   std::vector<int64_t> HArow;
@@ -1560,9 +1572,16 @@ GenLayout gen_layout(const wn_plan* p, int B, bool queued) {
   if (queued) {
     G.xin = cv.take((int64_t)p->KS * B);
     for (int b = 0; b < p->N; ++b) {
-      const int ns = (p->KS - 1) * p->blocks[b].dil.back().dil + 1;
+      const int ns = (p->KS - 1) * p->blocks[b].dil.front().dil + 1;
       G.nslots.push_back(ns);
       G.ring.push_back(cv.take((int64_t)ns * B * p->R));
+      G.ringp.emplace_back();
+      G.nslots_p.emplace_back();
+      for (int i = 1; i < p->LPB; ++i) {
+        const int nsi = (p->KS - 1) * p->blocks[b].dil[i].dil + 1;
+        G.nslots_p.back().push_back(nsi);
+        G.ringp.back().push_back(cv.take((int64_t)nsi * B * p->D));
+      }
     }
     G.Zrow = cv.take((int64_t)B * p->N * p->Dp);
     G.skiprow = cv.take((int64_t)B * p->Hin);
@@ -1608,11 +1627,6 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
                            int32_t length, int32_t deterministic, int32_t queued, uint64_t seed, float* out,
                            float* workspace, int64_t ws_floats, void* stream) {
   if (!p || !params || !window || !out || !workspace || B < 1 || length < 0) { wn_set_error("generate: bad arguments"); return WN_E_INVALID; }
-  if (queued && p->LPB != 1) {
-    // same limitation as the reference's own design (README.md:16, src/layers.py:226-290)
-    wn_set_error("queued generation supports one dilated convolution per block only");
-    return WN_E_UNSUPPORTED;
-  }
   hipStream_t s = (hipStream_t)stream;
   const int RF = wn_plan_receptive_field(p);
   const GenLayout G = gen_layout(p, B, queued != 0);
@@ -1653,7 +1667,13 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   //      the sliding window uses, so the results are identical ----
   GenRings R;
   R.xin = workspace + G.xin;
-  for (int b = 0; b < p->N; ++b) { R.h.push_back(workspace + G.ring[b]); R.nslots.push_back(G.nslots[b]); }
+  for (int b = 0; b < p->N; ++b) {
+    R.h.push_back(workspace + G.ring[b]);
+    R.nslots.push_back(G.nslots[b]);
+    R.hp.emplace_back();
+    for (int64_t off : G.ringp[b]) R.hp.back().push_back(workspace + off);
+    R.nslots_p.push_back(G.nslots_p[b]);
+  }
   rc = forward_core(p, params, win[0], true, cond, B, RF, false, pws, L, s, &R);
   if (rc) return rc;
   hipLaunchKernelGGL(wn_gather_last_kernel, dim3((B * p->Cout + 255) / 256), dim3(256), 0, s, pws + L.logits, B, RF, p->Cout, last);
@@ -1723,9 +1743,29 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       const int d = p->blocks[b].dil.back().dil;
       BlockBufs f;
       memset(&f, 0, sizeof(f));
+      // layers_per_block > 1 (the reference's stated blocker, README.md:16): every dilated conv of the
+      // stack has a ring of ITS inputs; the non-gated convs run here, one output row each, and feed the
+      // next ring's slot tau
+      const float* in_ring = R.h[b];
+      int in_ns = R.nslots[b], in_c = p->R;
+      for (int i = 0; i + 1 < p->LPB; ++i) {
+        const int di = p->blocks[b].dil[i].dil;
+        Gemm g(B, 1, p->D, ceil32(p->D));
+        for (int t = 0; t < p->KS; ++t)
+          g.seg(in_ring + (int64_t)((tau - (int64_t)(p->KS - 1 - t) * di) % in_ns) * B * in_c, in_c, in_c, 0,
+                k.Fd[i] + t * k.Fd_stride[i]);
+        float* dst = R.hp[b][i] + (int64_t)(tau % R.nslots_p[b][i]) * B * p->D;
+        rc = g.bias(k.bd[i]).act(k.act).run(dst, p->D, s);
+        if (rc) return rc;
+        in_ring = R.hp[b][i]; in_ns = R.nslots_p[b][i]; in_c = p->D;
+      }
       for (int t = 0; t < p->KS; ++t)
-        f.xt[t] = R.h[b] + (int64_t)((tau - (int64_t)(p->KS - 1 - t) * d) % R.nslots[b]) * B * p->R;
+        f.xt[t] = in_ring + (int64_t)((tau - (int64_t)(p->KS - 1 - t) * d) % in_ns) * B * in_c;
       f.x = f.xt[p->KS - 1];
+      if (p->LPB > 1) {
+        f.pre_done = true;
+        f.res = R.h[b] + (int64_t)(tau % R.nslots[b]) * B * p->R;     // the block input at time tau
+      }
       f.U = workspace + G.hrow1;
       f.AG = nullptr;
       f.Z = Zrow + (int64_t)b * B * p->Dp; f.ldz = p->Dp;
