@@ -535,3 +535,20 @@ def test_layer_dropout_training_mode():
     layer.flat_params.zero_()
   xo, _ = layer(x, training=True)
   assert torch.allclose(xo, x, atol=1e-6)
+
+
+def test_sound_callback_writes_ab_files(tmp_path):
+  """src/callbacks.py:51-118 with use_fast='both': queued and sliding-window audio side by side."""
+  import numpy as np
+  from wavenets_amd import WaveNet
+  from wavenets_amd.callbacks import SoundCallback
+  m = WaveNet(blocks=3, channels=32, skip_channels=32, dilation_bound=4, final_layers_channels=[], bits=8, device=dev())
+  cb = SoundCallback(str(tmp_path), 16000, 300, True, epoch_frequency=2, use_fast='both', model=m)
+  assert cb.on_epoch_end(0) is None                     # logged every 2nd epoch only
+  cb.on_epoch_end(1)
+  d = tmp_path / 'epoch_0001'
+  for key in ('fast', 'standard'):
+    wav = np.load(d / f'generated_{key}.npy')
+    assert wav.shape == (5, 300, 1) and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
+    assert np.load(d / f'generated_spectrogram_{key}.npy').shape == (5, 129, 1, 1)
+    assert (d / f'generated_{key}_4.wav').exists()

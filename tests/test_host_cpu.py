@@ -4,6 +4,7 @@ import math
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from wavenets_amd import callbacks, data, io
@@ -66,3 +67,51 @@ def test_training_policies():
   assert not e.on_epoch_end(95.0, m)
   assert e.on_epoch_end(96.0, m)            # stop, best weights restored
   assert torch.equal(m.flat_params.data, torch.ones(3))
+
+
+def test_create_spectrogram_matches_definition():
+  """src/callbacks.py:133-159: frame 256 / hop 128 / periodic Hann / log(|.|+1e-5), (B,129,frames,1), min-max."""
+  import numpy as np
+  from wavenets_amd.callbacks import create_spectrogram
+  rng = np.random.default_rng(0)
+  x = rng.standard_normal((3, 1000, 1)).astype(np.float32) * 0.1
+  got = create_spectrogram(torch.from_numpy(x))
+  frames = 1 + (1000 - 256) // 128
+  assert got.shape == (3, 129, frames, 1)
+  assert got.min() == 0.0 and abs(got.max() - 1.0) < 1e-6
+  # direct DFT of one frame
+  b, f, k = 1, 2, 17
+  w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(256) / 256)
+  seg = x[b, 128 * f:128 * f + 256, 0] * w
+  mag = abs(np.sum(seg * np.exp(-2j * np.pi * k * np.arange(256) / 256)))
+  # undo the min-max scaling with two reference points
+  raw = np.log(mag + 1e-5)
+  allraw = []
+  for bb in range(3):
+    for ff in range(frames):
+      s = x[bb, 128 * ff:128 * ff + 256, 0] * w
+      allraw.append(np.log(np.abs(np.fft.rfft(s)) + 1e-5))
+  allraw = np.array(allraw)
+  want = (raw - allraw.min()) / (allraw.max() - allraw.min())
+  assert abs(got[b, k, f, 0] - want) < 1e-4
+
+
+def test_write_wav_roundtrip(tmp_path):
+  import numpy as np
+  import wave
+  from wavenets_amd.callbacks import write_wav
+  x = np.sin(np.linspace(0, 20, 800)).astype(np.float32) * 0.5
+  p = str(tmp_path / 'a.wav')
+  write_wav(p, torch.from_numpy(x)[:, None], 16000)
+  with wave.open(p, 'rb') as f:
+    assert f.getframerate() == 16000 and f.getnchannels() == 1 and f.getsampwidth() == 2
+    pcm = np.frombuffer(f.readframes(f.getnframes()), dtype='<i2')
+  assert pcm.shape[0] == 800 and np.abs(pcm / 32768.0 - x).max() < 1e-4
+
+
+def test_sound_callback_argument_checks():
+  from wavenets_amd.callbacks import SoundCallback
+  with pytest.raises(ValueError, match='use_fast'):
+    SoundCallback('x', 16000, 10, True, use_fast='maybe')
+  with pytest.raises(ValueError, match='epoch_frequency'):
+    SoundCallback('x', 16000, 10, True, epoch_frequency=0)
