@@ -86,6 +86,16 @@ struct WnWgJob {
   int64_t gmax_off;                          // workspace offset of the running max-abs of g, or < 0
   int32_t ldx, ldg, K, N, shift, k0, n0, pad_;
 };
+// dW_d (both taps), db_d, dW_r, db_r of one residual block per workgroup (wn_wgrad_layer.hip)
+struct WnWgLayer {
+  int64_t x_off, du_off, z_off, go_off;         // workspace offsets: [rows][R], [rows][2D], [rows][ldz], [rows][R]
+  int64_t dwd_off, dbd_off, dwr_off, dbr_off;   // offsets inside a slab row (= flat gradient layout)
+  int64_t gmax_u_off, gmax_h_off;               // running max-abs of du / go, or < 0
+  int32_t dilation, ldz;
+};
+int wn_wgrad_layer_supported(int R, int D, int KS);
+int wn_launch_wgrad_layers(const WnWgLayer* d_layers, int nlayers, int R, float* ws, float* slab, int64_t P, int B,
+                           int T, int splits_per_b, hipStream_t s);
 // dW_s / db_s of the folded skip path for all blocks (wn_wgrad_skip.hip)
 int wn_wgrad_skip_supported(int D, int S, int KZ);
 int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64_t rows, int KZ, int S, int D,

@@ -79,6 +79,8 @@ struct wn_plan {
   int njobs = 0, ncov = 0, jobs_B = 0, jobs_T = 0, jobs_splits = 0;
   bool jobs_drop = false;
   bool jobs_skipk = false;
+  bool jobs_layerk = false;   // per-block dW_d / dW_r come from the layer weight-gradient kernel
+  WnWgLayer* d_wgl = nullptr;
   WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
   int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
@@ -844,6 +846,7 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
+  if (p->d_wgl) (void)hipFree(p->d_wgl);
   if (p->d_gen) (void)hipFree(p->d_gen);
   delete p;
 }
@@ -1153,8 +1156,12 @@ bool skip_kernel_ok(const wn_plan* p) {
 
 int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool skipk = skip_kernel_ok(p);
+  // knob 8 = 1 keeps the per-block weight gradients on the generic job table
+  const bool layerk = wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1 &&
+                      wn_debug_get(3) != 1 && wn_debug_get(8) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
-      p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk) return WN_OK;
+      p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk) return WN_OK;
+  std::vector<WnWgLayer> wgl;
   std::vector<WnWgJob> jobs;
   std::vector<WnTensorDesc> cov;
   auto cover = [&](int t) { WnTensorDesc d; d.off = p->tensors[t].off; d.len = p->tensors[t].len; cov.push_back(d); };
@@ -1172,15 +1179,27 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   for (int b = 0; b < p->N; ++b) {
     const BlockInfo& bi = p->blocks[b];
     const ConvInfo& c = bi.dil[0];
+    const int64_t zoff = L.Z + (int64_t)b * B * T * p->Dp;      // block-major Z
+    if (layerk) {
+      WnWgLayer w;
+      w.x_off = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
+      w.du_off = L.GU[b]; w.z_off = zoff; w.ldz = p->Dp;
+      w.go_off = p->S == 0 ? L.GO[b] : L.GH[b + 1];
+      w.dwd_off = p->tensors[c.kernel_t].off; w.dbd_off = p->tensors[c.bias_t].off;
+      w.dwr_off = p->tensors[bi.conv1.kernel_t].off; w.dbr_off = p->tensors[bi.conv1.bias_t].off;
+      w.gmax_u_off = am_GU(b); w.gmax_h_off = p->S == 0 ? am_skip : am_GH(b + 1);
+      w.dilation = c.dil;
+      wgl.push_back(w);
+    } else {
     for (int t = 0; t < p->KS; ++t)
       add_jobs(jobs, p->drop_rate > 0.f ? L.XD[b] : L.H[b], p->R, p->R, (p->KS - 1 - t) * c.dil, L.GU[b], 2 * p->D, 2 * p->D,
                p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D,
                t == p->KS - 1 ? p->tensors[c.bias_t].off : -1, am_GU(b));
-    cover(c.kernel_t); cover(c.bias_t);
-    const int64_t zoff = L.Z + (int64_t)b * B * T * p->Dp;      // block-major Z
     // S == 0: g_o = g_xout + g_skip (or a copy of g_skip): bounded by twice the larger max-abs -> no slot
     add_jobs(jobs, zoff, p->Dp, p->D, 0, p->S == 0 ? L.GO[b] : L.GH[b + 1], p->R, p->R,
              p->tensors[bi.conv1.kernel_t].off, p->tensors[bi.conv1.bias_t].off, p->S == 0 ? am_skip : am_GH(b + 1));
+    }
+    cover(c.kernel_t); cover(c.bias_t);
     cover(bi.conv1.kernel_t); cover(bi.conv1.bias_t);
     if (bi.has_skip && p->c.use_skip) {
       if (!skipk)
@@ -1202,6 +1221,12 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   WN_HIP_CHECK(hipMemcpy(p->d_jobs, jobs.data(), jobs.size() * sizeof(WnWgJob), hipMemcpyHostToDevice));
   WN_HIP_CHECK(hipMalloc((void**)&p->d_cov, cov.size() * sizeof(WnTensorDesc)));
   WN_HIP_CHECK(hipMemcpy(p->d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+  if (p->d_wgl) { (void)hipFree(p->d_wgl); p->d_wgl = nullptr; }
+  if (!wgl.empty()) {
+    WN_HIP_CHECK(hipMalloc((void**)&p->d_wgl, wgl.size() * sizeof(WnWgLayer)));
+    WN_HIP_CHECK(hipMemcpy(p->d_wgl, wgl.data(), wgl.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
+  }
+  p->jobs_layerk = layerk;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
   p->jobs_skipk = skipk;
@@ -1382,6 +1407,10 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     }
     rc = wn_launch_wgrad_batched(p->d_jobs, p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
     if (rc) return rc;
+    if (p->jobs_layerk) {
+      rc = wn_launch_wgrad_layers(p->d_wgl, p->N, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
+      if (rc) return rc;
+    }
     if (p->jobs_skipk) {
       const BlockInfo& b0 = p->blocks[0];
       const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
