@@ -81,6 +81,9 @@ struct wn_plan {
   bool jobs_skipk = false;
   bool jobs_layerk = false;   // per-block dW_d / dW_r come from the layer weight-gradient kernel
   WnWgLayer* d_wgl = nullptr;
+  // side stream: the low-occupancy generic weight-gradient jobs overlap the per-block / skip kernels
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
   int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
@@ -847,6 +850,9 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
   if (p->d_wgl) (void)hipFree(p->d_wgl);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  if (p->side) (void)hipStreamDestroy(p->side);
   if (p->d_gen) (void)hipFree(p->d_gen);
   delete p;
 }
@@ -1405,8 +1411,22 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         if (rc) return rc;
       }
     }
-    rc = wn_launch_wgrad_batched(p->d_jobs, p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
+    // the generic jobs left over (input conv, head) are few single-wave jobs: they run beside the
+    // per-block and skip kernels on a side stream (disjoint slab regions), joined before the reduce.
+    // knob 9 = 1 keeps everything on the caller's stream.
+    const bool fork = p->jobs_layerk && wn_debug_get(9) != 1;
+    if (fork && !p->side) {
+      WN_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+      WN_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+      WN_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
+    if (fork) {
+      WN_HIP_CHECK(hipEventRecord(p->ev_fork, s));
+      WN_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+    }
+    rc = wn_launch_wgrad_batched(p->d_jobs, p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, fork ? p->side : s);
     if (rc) return rc;
+    if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
     if (p->jobs_layerk) {
       rc = wn_launch_wgrad_layers(p->d_wgl, p->N, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
       if (rc) return rc;
@@ -1420,6 +1440,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
                                 p->tensors[b0.conv_skip.bias_t].off, bst, p->N, am_gskip, s);
       if (rc) return rc;
     }
+    if (fork) WN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0));
     rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov, p->ncov, s);
     if (rc) return rc;
     if (!p->c.use_skip && p->S > 0) {
