@@ -1,0 +1,23 @@
+"""Training-step time of BASELINE configs[1] under a debug knob setting: python tools/knob_bench.py KEY VAL [KEY VAL ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from wavenets_amd import WaveNet, Adam, _lib
+from oracle import wavenet_oracle as O
+L = _lib.lib()
+args = [int(a) for a in sys.argv[1:]]
+for k, v in zip(args[0::2], args[1::2]):
+  L.wn_debug_set(k, v)
+dev = torch.device('cuda', 0)
+m = WaveNet(**bench.CFG2, device=dev)
+m.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
+x = O.synthetic_waveform(8, 16001, seed=1).to(dev)
+for _ in range(4):
+  m.train_step(x)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+  m.train_step(x)
+torch.cuda.synchronize()
+print(f'knobs {args}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step')

@@ -33,6 +33,13 @@ __device__ __forceinline__ void wn_split8g(const f32x4& q0, const f32x4& q1, flo
   }
 }
 
+// global-address-space 16-byte load.  Pointers that went through a per-segment select lose their
+// address space and hipcc emits flat_load: flat loads also count on lgkmcnt, so every LDS fragment
+// wait would drain the activation prefetch, and the compiler waits vmcnt(0) while one is pending.
+__device__ __forceinline__ f32x4 wn_ldg4(const float* p) {
+  return *(const __attribute__((address_space(1))) f32x4*)(p);
+}
+
 // chunk = CH (k-step, row-tile) blocks of 2 KiB  ->  KSC = CH / JT k-steps per chunk
 template <int JT>
 struct WnG16 {
@@ -43,7 +50,8 @@ struct WnG16 {
   static constexpr int PITCH = SC + 4;
   static constexpr int STAGE_BYTES = 32 * PITCH * 4;  // 8704
   static constexpr int WAVES = 8;
-  static constexpr int LDS_BYTES = 2 * CHUNK_BYTES + WAVES * STAGE_BYTES;   // 135168
+  static constexpr int NBUF = 4;                      // weight ring: chunk c lives in buffer c % NBUF, two chunks in flight
+  static constexpr int LDS_BYTES = NBUF * CHUNK_BYTES + WAVES * STAGE_BYTES;   // 135168
 };
 
 // epilogue shared by the streamed and the resident kernels: bias / row bias / residual / activation
@@ -81,17 +89,17 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
               v[0] = acc[j < JT ? j : 0][4 * rq + 0] * inv_sc; v[1] = acc[j < JT ? j : 0][4 * rq + 1] * inv_sc;
               v[2] = acc[j < JT ? j : 0][4 * rq + 2] * inv_sc; v[3] = acc[j < JT ? j : 0][4 * rq + 3] * inv_sc;
               if (a.bias) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n0);
+                const f32x4 bv = wn_ldg4(a.bias + n0);
                 v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
               }
               if (a.rowbias) {
-                const f32x4 rb = *reinterpret_cast<const f32x4*>(a.rowbias + (int64_t)b * a.ld_rowbias + n0);
+                const f32x4 rb = wn_ldg4(a.rowbias + (int64_t)b * a.ld_rowbias + n0);
                 v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
               }
               if (a.addc) {
                 f32x4 cv;
                 if constexpr (PRE == 1) cv = pre->addc[j < JT ? j : 0][rq];
-                else cv = *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0);
+                else cv = wn_ldg4(a.addc + row * a.ld_addc + n0);
                 v[0] += cv.x; v[1] += cv.y; v[2] += cv.z; v[3] += cv.w;
               }
               if (a.epi == WN_EPI_PLAIN) {
@@ -100,7 +108,7 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
               } else if (a.epi == WN_EPI_DACT) {
                 f32x4 yv;
                 if constexpr (PRE == 3) yv = pre->aux[j < JT ? j : 0][rq];
-                else yv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
+                else yv = wn_ldg4(a.aux + row * a.ld_aux + n0);
                 v[0] *= wn_dact_from_y(yv.x, a.act); v[1] *= wn_dact_from_y(yv.y, a.act);
                 v[2] *= wn_dact_from_y(yv.z, a.act); v[3] *= wn_dact_from_y(yv.w, a.act);
               } else {
@@ -109,8 +117,8 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
                   gv = pre->aux[j < JT ? j : 0][rq];
                   zv = pre->aux2[j < JT ? j : 0][rq];
                 } else {
-                  gv = *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0);
-                  zv = *reinterpret_cast<const f32x4*>(a.aux2 + row * a.ld_aux2 + n0);
+                  gv = wn_ldg4(a.aux + row * a.ld_aux + n0);
+                  zv = wn_ldg4(a.aux2 + row * a.ld_aux2 + n0);
                 }
                 // each pass evaluates only the derivative it stores (filter half, then gate half)
                 if (part == 0) {
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tl = lane & 31, h = lane >> 5;
-  float* stage = reinterpret_cast<float*>(smem + 2 * G::CHUNK_BYTES + wave * G::STAGE_BYTES);
+  float* stage = reinterpret_cast<float*>(smem + G::NBUF * G::CHUNK_BYTES + wave * G::STAGE_BYTES);
 
   // exact power-of-two operand scale from the producers' running max-abs
   float sc = 1.0f, inv_sc = 1.0f;
@@ -184,8 +192,22 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
   const int tiles_per_b = (a.T + 31) >> 5;
   const int64_t ntiles = (int64_t)a.B * tiles_per_b;
   const int nchunks = (nks_total + KSC - 1) / KSC;
-  const int64_t passes = (ntiles + (int64_t)gridDim.x * G::WAVES - 1) / ((int64_t)gridDim.x * G::WAVES);
-  const int jb = blockIdx.y * JT;                      // first row tile of this block (N > 32*JT)
+  // 1-D grid of (row group, column block) pairs.  Workgroup ids that differ by 8 land on the same XCD
+  // (round-robin dispatch), so the column blocks of one row group are placed 8 ids apart: they run
+  // at the same time behind the same L2 and the rows are fetched from HBM once, not once per column block.
+  const int ny = (a.JTtot + JT - 1) / JT;
+  const int gxw = gridDim.x / ny;                      // workgroups per column block
+  int xb, cb;
+  if (ny > 1 && gxw % 8 == 0) {
+    const int grp = blockIdx.x / (8 * ny), rem = blockIdx.x % (8 * ny);
+    cb = rem / 8;
+    xb = grp * 8 + rem % 8;
+  } else {
+    cb = blockIdx.x % ny;
+    xb = blockIdx.x / ny;
+  }
+  const int64_t passes = (ntiles + (int64_t)gxw * G::WAVES - 1) / ((int64_t)gxw * G::WAVES);
+  const int jb = cb * JT;                              // first row tile of this block (N > 32*JT)
 
   // k-step boundaries of the segments (static indices: no private-memory copy of the args)
   int ks_end[WN_MAXSEG];
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
   float wmax = 0.f;
 
   for (int64_t pass = 0; pass < passes; ++pass) {
-    const int64_t tile = (pass * gridDim.x + blockIdx.x) * G::WAVES + wave;
+    const int64_t tile = (pass * gxw + xb) * G::WAVES + wave;
     const bool live = tile < ntiles;                   // dead waves still take part in the barriers
     const int b = live ? (int)(tile / tiles_per_b) : 0;
     const int t0 = live ? (int)(tile % tiles_per_b) * 32 : 0;
@@ -224,23 +246,23 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
       }
     }
     // activations of global k-step ks for this lane: two float4 quads (channels 16kk+4h.., 16kk+8+4h..)
-    auto load_x = [&](int ks, f32x4& q0, f32x4& q1) {
-      q0 = f32x4{0.f, 0.f, 0.f, 0.f};
-      q1 = q0;
-      if (ks >= nks_total) return;
+    // The loads are unconditional (clamped k-step, clamped row; zeroed afterwards): the pipeline below
+    // relies on every chunk issuing the same vector-memory instructions in the same order.
+    auto load_x = [&](int ks_in, f32x4& q0, f32x4& q1, bool& okout) {
+      const int ks = min(ks_in, nks_total - 1);
       const float* xr = xrow_s[0];
       bool ok = xok_s[0];
       int kk = ks;
 #pragma unroll
       for (int s = 1; s < WN_MAXSEG; ++s)
         if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }   // wave-uniform
-      if (ok) {
-        if (plane_ks0 > 0 && ks < ks_end[0]) xr += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
-        q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
-        q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
-      }
+      ok = ok && ks_in < nks_total;
+      if (plane_ks0 > 0 && ks < ks_end[0]) xr += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
+      q0 = wn_ldg4(xr + 16 * kk);
+      q1 = wn_ldg4(xr + 16 * kk + 8);
+      okout = ok;                                      // zeroed where it is consumed, not here (no early wait)
     };
-    // weight chunk c: global -> LDS buffer (c & 1) by LDS-DMA (no registers): every wave instruction
+    // weight chunk c: global -> LDS buffer (c % NBUF) by LDS-DMA (no registers): every wave instruction
     // moves one contiguous KiB (wave-uniform LDS base + lane * 16).  Blocks past the end of the image
     // are clamped to a valid block: their activations are zero, so they only need to be finite.
     auto wdma = [&](int c) {
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
         ks = min(ks, nks_total - 1);
         j = min(j, a.JTtot - 1);
         const f32x4* src = reinterpret_cast<const f32x4*>(w16) + ((int64_t)ks * a.JTtot + j) * 128 + within;
-        unsigned char* dst = smem + (c & 1) * G::CHUNK_BYTES + (512 * i + wave * 64) * 16;   // wave-uniform
+        unsigned char* dst = smem + (c % G::NBUF) * G::CHUNK_BYTES + (512 * i + wave * 64) * 16;   // wave-uniform
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
@@ -265,15 +287,30 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    // Pipeline.  vmcnt retires in order, so the ISSUE ORDER  dma(c), x(c), dma(c+1) | x(c+1), dma(c+2) | ...
+    // makes "x(c) has arrived" imply "dma(c) has arrived" while dma(c+1) and dma(c+2) stay in flight:
+    // touching x(c) before the barrier is the whole synchronisation (the compiler counts the
+    // instructions issued since).  One raw barrier per chunk; a wave can be at most one chunk ahead of
+    // the slowest one, so buffer (c+2) % 4 is never one that is still being read.
     f32x4 xa[KSC][2], xb[KSC][2];
-    __syncthreads();                                   // previous pass finished with both buffers
+    bool oka[KSC], okb[KSC];
+    __syncthreads();                                   // previous pass finished with every buffer
     wdma(0);
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < KSC; ++k) load_x(k, xa[k][0], xa[k][1]);
-    __syncthreads();                                   // (the barrier's fence drains the DMA: vmcnt(0))
+    for (int k = 0; k < KSC; ++k) load_x(k, xa[k][0], xa[k][1], oka[k]);
+    asm volatile("" ::: "memory");
+    if (1 < nchunks) wdma(1);
+    asm volatile("" ::: "memory");
+    auto arrive = [&](const f32x4 (&xv)[KSC][2]) {
+      // a use of the LAST activation register of the chunk: the compiler's own s_waitcnt for it covers
+      // every earlier request, including this chunk's weight DMA
+      asm volatile("" ::"v"(xv[KSC - 1][1].w));
+      asm volatile("s_barrier" ::: "memory");
+    };
 
-    auto compute = [&](int c, const f32x4 (&xv)[KSC][2]) {
-      const h8* wl = reinterpret_cast<const h8*>(smem + (c & 1) * G::CHUNK_BYTES) + lane;
+    auto compute = [&](int c, const f32x4 (&xv)[KSC][2], const bool (&okv)[KSC]) {
+      const h8* wl = reinterpret_cast<const h8*>(smem + (c % G::NBUF) * G::CHUNK_BYTES) + lane;
       // (k-step, tile) blocks in order; the next block's hi|lo fragments are read one block ahead and
       // the schedule is pinned per block so that the compiler does not hoist a whole chunk of LDS reads
       h8 fr[2][2];
@@ -287,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
           fr[(blk + 1) & 1][1] = wl[((blk + 1) * 2 + 1) * 64];
         }
         h8 bh, bl;
-        wn_split8g(xv[k][0], xv[k][1], sc, bh, bl);
+        wn_split8g(xv[k][0], xv[k][1], okv[k] ? sc : 0.f, bh, bl);       // masked rows / k-steps contribute zero
         acc[j] = wn_mfma16g(fr[blk & 1][1], bh, acc[j]);
         acc[j] = wn_mfma16g(fr[blk & 1][0], bl, acc[j]);
         acc[j] = wn_mfma16g(fr[blk & 1][0], bh, acc[j]);
@@ -295,23 +332,27 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
       });
     };
     for (int c = 0; c < nchunks; c += 2) {
-      // ---- even chunk: operands xa, prefetch into xb ----
+      // ---- even chunk: operands xa; request x(c+1) into xb, then weights of chunk c+2 ----
       if (c + 1 < nchunks) {
-        wdma(c + 1);
 #pragma unroll
-        for (int k = 0; k < KSC; ++k) load_x((c + 1) * KSC + k, xb[k][0], xb[k][1]);
+        for (int k = 0; k < KSC; ++k) load_x((c + 1) * KSC + k, xb[k][0], xb[k][1], okb[k]);
       }
-      compute(c, xa);
-      __syncthreads();
+      asm volatile("" ::: "memory");
+      if (c + 2 < nchunks) wdma(c + 2);
+      asm volatile("" ::: "memory");
+      arrive(xa);
+      compute(c, xa, oka);
       if (c + 1 >= nchunks) break;
-      // ---- odd chunk: operands xb, prefetch into xa ----
+      // ---- odd chunk: operands xb; request x(c+2) into xa, then weights of chunk c+3 ----
       if (c + 2 < nchunks) {
-        wdma(c + 2);
 #pragma unroll
-        for (int k = 0; k < KSC; ++k) load_x((c + 2) * KSC + k, xa[k][0], xa[k][1]);
+        for (int k = 0; k < KSC; ++k) load_x((c + 2) * KSC + k, xa[k][0], xa[k][1], oka[k]);
       }
-      compute(c + 1, xb);
-      __syncthreads();
+      asm volatile("" ::: "memory");
+      if (c + 3 < nchunks) wdma(c + 3);
+      asm volatile("" ::: "memory");
+      arrive(xb);
+      compute(c + 1, xb, okb);
     }
 
     if (live) wn_g16_epilogue<JT, PITCH>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
@@ -393,8 +434,8 @@ __global__ __launch_bounds__(64) void wn_gemm_rows16_thin_kernel(WnGemmArgs a, c
       if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }
     if (ok) {
       if (plane_ks0 > 0 && ks < ks_end[0]) xr += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
-      q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
-      q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
+      q0 = wn_ldg4(xr + 16 * kk);
+      q1 = wn_ldg4(xr + 16 * kk + 8);
     }
   };
   // hi|lo fragments of (k-step, column tile jb); k-steps past the end are clamped (their activations are zero)
@@ -531,8 +572,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
     for (int s = 1; s < WN_MAXSEG; ++s)
       if (ks >= ks_end[s - 1]) { xr = c.xrow_s[s]; ok = c.xok_s[s]; kk = ks - ks_end[s - 1]; }
     if (ok) {
-      q0 = *reinterpret_cast<const f32x4*>(xr + 16 * kk);
-      q1 = *reinterpret_cast<const f32x4*>(xr + 16 * kk + 8);
+      q0 = wn_ldg4(xr + 16 * kk);
+      q1 = wn_ldg4(xr + 16 * kk + 8);
     }
   };
   const int64_t tstride = (int64_t)gridDim.x * G::WAVES;
@@ -556,10 +597,10 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
         for (int rq = 0; rq < 4; ++rq) {
           const int n0 = 32 * j + 8 * rq + 4 * h;
           const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (PREK == 1) pre.addc[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.addc + row * a.ld_addc + n0) : z4;
+          if constexpr (PREK == 1) pre.addc[j][rq] = tin ? wn_ldg4(a.addc + row * a.ld_addc + n0) : z4;
           if constexpr (PREK == 2) {
-            pre.aux[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.aux + row * a.ld_aux + n0) : z4;
-            pre.aux2[j][rq] = tin ? *reinterpret_cast<const f32x4*>(a.aux2 + row * a.ld_aux2 + n0) : z4;
+            pre.aux[j][rq] = tin ? wn_ldg4(a.aux + row * a.ld_aux + n0) : z4;
+            pre.aux2[j][rq] = tin ? wn_ldg4(a.aux2 + row * a.ld_aux2 + n0) : z4;
           }
         }
     }
@@ -653,7 +694,7 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
     hipLaunchKernelGGL(wn_gemm_rows16_kernel<2>, dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   } else {
     // 128 output channels per workgroup column; wider outputs re-read the activations per column
-    hipLaunchKernelGGL(wn_gemm_rows16_kernel<4>, dim3((unsigned)gx, (jt_need + 3) / 4), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    hipLaunchKernelGGL(wn_gemm_rows16_kernel<4>, dim3((unsigned)(gx * ((a.JTtot + 3) / 4)), 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;

@@ -349,6 +349,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
       int sp = (int)((5000 + (int64_t)nj * B - 1) / ((int64_t)nj * B));
       const int maxsp = std::max(1, (T + 255) / 256);
       sp = std::max(1, std::min(sp, maxsp));
+      if (wn_debug_get(10) > 0) sp = std::max(1, std::min(wn_debug_get(10), maxsp));   // knob 10: time splits per utterance
       L.bsplits = sp;
       L.bslab = cv.take((int64_t)B * sp * p->nparams);
     }
