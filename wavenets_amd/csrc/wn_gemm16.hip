@@ -525,24 +525,20 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
       inv_sc = ldexpf(1.0f, e);
     }
   }
-  int ks_end[WN_MAXSEG];
-  {
-    int acc = 0;
-#pragma unroll
-    for (int s = 0; s < WN_MAXSEG; ++s) {
-      if (s < a.nseg) acc += (a.seg[s].K + 15) >> 4;
-      ks_end[s] = acc;
-    }
-  }
+  // Segment fields are read straight from the kernel-argument block by wave-uniform selects (scalar
+  // loads).  Copies of them in local arrays or captured locals end up in scratch memory once the
+  // k-step that indexes them is a runtime value, and every activation load then waits for a scratch
+  // load first (s_waitcnt vmcnt(0) per load).
+  static_assert(WN_MAXSEG == 4, "segment select below is written out for four segments");
+  const int e0 = (a.seg[0].K + 15) >> 4;
+  const int e1 = a.nseg > 1 ? e0 + ((a.seg[1].K + 15) >> 4) : nks_total;
+  const int e2 = a.nseg > 2 ? e1 + ((a.seg[2].K + 15) >> 4) : nks_total;
   float wmax = 0.f;
   const int tiles_per_b = (a.T + 31) >> 5;
   const int64_t ntiles = (int64_t)a.B * tiles_per_b;
-  // per-tile geometry + row pointers of this lane
   struct TileCtx {
     int b, t, rows_valid;
     int64_t row0;
-    const float* xrow_s[WN_MAXSEG];
-    bool xok_s[WN_MAXSEG];
   };
   auto make_ctx = [&](int64_t tile, TileCtx& c) {
     c.b = (int)(tile / tiles_per_b);
@@ -550,57 +546,53 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
     c.t = t0 + tl;
     c.rows_valid = min(32, a.T - t0);
     c.row0 = (int64_t)c.b * a.T + t0;
-#pragma unroll
-    for (int s = 0; s < WN_MAXSEG; ++s) {
-      c.xrow_s[s] = nullptr;
-      c.xok_s[s] = false;
-      if (s < a.nseg) {
-        const int ts = c.t - a.seg[s].shift;
-        c.xok_s[s] = c.t < a.T && ts >= 0 && ts < a.T;
-        c.xrow_s[s] = a.seg[s].x + ((int64_t)c.b * a.T + (c.xok_s[s] ? ts : 0)) * a.seg[s].ldx + 4 * h;
-      }
-    }
   };
-  auto load_x = [&](const TileCtx& c, int ks, f32x4& q0, f32x4& q1) {
-    q0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    q1 = q0;
-    if (ks >= nks_total) return;
-    const float* xr = c.xrow_s[0];
-    bool ok = c.xok_s[0];
-    int kk = ks;
-#pragma unroll
-    for (int s = 1; s < WN_MAXSEG; ++s)
-      if (ks >= ks_end[s - 1]) { xr = c.xrow_s[s]; ok = c.xok_s[s]; kk = ks - ks_end[s - 1]; }
-    if (ok) {
-      q0 = wn_ldg4(xr + 16 * kk);
-      q1 = wn_ldg4(xr + 16 * kk + 8);
-    }
+  // straight-line, unconditional (k-step inside [0, nks_total): the launcher guarantees nks_total % PF == 0;
+  // masked rows read a clamped row and are zeroed where they are consumed)
+  auto load_x = [&](const TileCtx& c, int ks, f32x4& q0, f32x4& q1, bool& okout) {
+    const int si = (ks >= e0) + (ks >= e1) + (ks >= e2);               // wave-uniform segment index
+    const int kk = ks - (si == 0 ? 0 : si == 1 ? e0 : si == 2 ? e1 : e2);
+    const float* bx = a.seg[si].x;
+    const int ld = a.seg[si].ldx, sh = a.seg[si].shift;
+    const int ts = c.t - sh;
+    const bool ok = c.t < a.T && ts >= 0 && ts < a.T;
+    const float* src = bx + ((int64_t)c.b * a.T + (ok ? ts : 0)) * ld + 4 * h + 16 * kk;
+    q0 = wn_ldg4(src);
+    q1 = wn_ldg4(src + 8);
+    okout = ok;
   };
   const int64_t tstride = (int64_t)gridDim.x * G::WAVES;
   int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
-  TileCtx cur;
-  f32x4 xa[PF][2], xb[PF][2];
+  // Rolling activation ring: slot k holds k-step (i mod PF == k).  Per k-step: the slot is turned into
+  // fp16 hi | lo operands (the compiler's counted s_waitcnt leaves the PF - 1 newer requests in flight),
+  // re-issued for k-step i + PF -- of this tile or, past its end, of the wave's next tile -- and only
+  // then the MFMAs run.  PF - 1 k-steps are in flight at all times, tile boundaries included.  All loads
+  // are straight-line and unconditional: a branch around a load makes hipcc wait vmcnt(0) per load.
+  TileCtx cur, nxt;
+  f32x4 xr_[PF][2];
+  bool okr[PF];
   if (tile < ntiles) {
     make_ctx(tile, cur);
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load_x(cur, k, xa[k][0], xa[k][1]);
+    for (int k = 0; k < PF; ++k) load_x(cur, k, xr_[k][0], xr_[k][1], okr[k]);
   }
   for (; tile < ntiles; tile += tstride) {
+    const bool has_next = tile + tstride < ntiles;     // wave-uniform
+    if (has_next) make_ctx(tile + tstride, nxt);
     // ---- epilogue operands of THIS tile, issued before the contraction (latency hidden under it) ----
     WnG16Pre<JT> pre;
     {
-      const bool tin = cur.t < a.T;
-      const int64_t row = cur.row0 + tl;
+      // rows past the end of the utterance read the tile's first row: the epilogue never uses them
+      const int64_t row = cur.row0 + (cur.t < a.T ? tl : 0);
 #pragma unroll
       for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const int n0 = 32 * j + 8 * rq + 4 * h;
-          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (PREK == 1) pre.addc[j][rq] = tin ? wn_ldg4(a.addc + row * a.ld_addc + n0) : z4;
+          if constexpr (PREK == 1) pre.addc[j][rq] = wn_ldg4(a.addc + row * a.ld_addc + n0);
           if constexpr (PREK == 2) {
-            pre.aux[j][rq] = tin ? wn_ldg4(a.aux + row * a.ld_aux + n0) : z4;
-            pre.aux2[j][rq] = tin ? wn_ldg4(a.aux2 + row * a.ld_aux2 + n0) : z4;
+            pre.aux[j][rq] = wn_ldg4(a.aux + row * a.ld_aux + n0);
+            pre.aux2[j][rq] = wn_ldg4(a.aux2 + row * a.ld_aux2 + n0);
           }
         }
     }
@@ -609,42 +601,28 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
     for (int j = 0; j < JT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    auto compute = [&](int ks0, const f32x4 (&xv)[PF][2]) {
+    for (int ks0 = 0; ks0 < nks_total; ks0 += PF) {
+      wn_static_for<PF>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        h8 bh, bl;
+        wn_split8g(xr_[k][0], xr_[k][1], okr[k] ? sc : 0.f, bh, bl);    // masked rows contribute zero
+        __builtin_amdgcn_sched_barrier(0);
+        const int ksn = ks0 + k + PF;
+        if (ksn < nks_total) load_x(cur, ksn, xr_[k][0], xr_[k][1], okr[k]);
+        else if (has_next) load_x(nxt, ksn - nks_total, xr_[k][0], xr_[k][1], okr[k]);
 #pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        if (ks0 + k < nks_total) {                       // wave-uniform
-          h8 bh, bl;
-          wn_split8g(xv[k][0], xv[k][1], sc, bh, bl);
-#pragma unroll
-          for (int j = 0; j < JT; ++j) {
-            const h8 ah = wl[(((ks0 + k) * JT + j) * 2 + 0) * 64];
-            const h8 al = wl[(((ks0 + k) * JT + j) * 2 + 1) * 64];
-            acc[j] = wn_mfma16g(al, bh, acc[j]);
-            acc[j] = wn_mfma16g(ah, bl, acc[j]);
-            acc[j] = wn_mfma16g(ah, bh, acc[j]);
-          }
+        for (int j = 0; j < JT; ++j) {
+          const h8 ah = wl[(((ks0 + k) * JT + j) * 2 + 0) * 64];
+          const h8 al = wl[(((ks0 + k) * JT + j) * 2 + 1) * 64];
+          acc[j] = wn_mfma16g(al, bh, acc[j]);
+          acc[j] = wn_mfma16g(ah, bl, acc[j]);
+          acc[j] = wn_mfma16g(ah, bh, acc[j]);
         }
-      }
-    };
-    bool x_in_a = true;                                  // which register set holds the last computed chunk
-    for (int ks0 = 0; ks0 < nks_total; ks0 += 2 * PF) {
-#pragma unroll
-      for (int k = 0; k < PF; ++k) load_x(cur, ks0 + PF + k, xb[k][0], xb[k][1]);
-      compute(ks0, xa);
-      if (ks0 + PF >= nks_total) break;
-#pragma unroll
-      for (int k = 0; k < PF; ++k) load_x(cur, ks0 + 2 * PF + k, xa[k][0], xa[k][1]);
-      compute(ks0 + PF, xb);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
-    (void)x_in_a;
-    // ---- next tile's first activations go in flight before this tile's epilogue and stores ----
-    const TileCtx done = cur;
-    if (tile + tstride < ntiles) {
-      make_ctx(tile + tstride, cur);
-#pragma unroll
-      for (int k = 0; k < PF; ++k) load_x(cur, k, xa[k][0], xa[k][1]);
-    }
-    wn_g16_epilogue<JT, PITCH, PREK>(a, acc, inv_sc, 0, done.b, done.t, done.row0, done.rows_valid, stage, lane, wmax, &pre);
+    wn_g16_epilogue<JT, PITCH, PREK>(a, acc, inv_sc, 0, cur.b, cur.t, cur.row0, cur.rows_valid, stage, lane, wmax, &pre);
+    if (has_next) cur = nxt;
   }
   if (absmax_out) {
 #pragma unroll
@@ -683,6 +661,7 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   }
   // knob 2 = 1 disables the resident form
   if (jt_need == 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1 &&
+      nks % WnG16R<2>::PF == 0 &&
       a.seg[0].plane_k == 0) {
     if (a.epi == WN_EPI_GATE_BWD && !a.addc)
       hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 2>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
