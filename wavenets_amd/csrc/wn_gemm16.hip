@@ -43,9 +43,10 @@ __device__ __forceinline__ f32x4 wn_ldg4(const float* p) {
 // chunk = CH (k-step, row-tile) blocks of 2 KiB  ->  KSC = CH / JT k-steps per chunk
 template <int JT>
 struct WnG16 {
-  static constexpr int CH = 8;                        // blocks per chunk
-  static constexpr int KSC = CH / JT;                 // k-steps per chunk: 4, 2 for JT = 2, 4
-  static constexpr int CHUNK_BYTES = CH * 2048;       // 16 KiB
+  static constexpr int KSC = 2;                       // k-steps per chunk
+  static constexpr int CH = KSC * JT;                 // (k-step, row-tile) blocks per chunk
+  static constexpr int CHUNK_BYTES = CH * 2048;       // 8 / 16 KiB of weights for JT = 2 / 4
+  static constexpr int XBUF_BYTES = KSC * 2 * 1024;   // one chunk of a wave's activations (two fit in its stage)
   static constexpr int SC = 64;                       // stage width in channels
   static constexpr int PITCH = SC + 4;
   static constexpr int STAGE_BYTES = 32 * PITCH * 4;  // 8704
@@ -209,17 +210,19 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
   const int64_t passes = (ntiles + (int64_t)gxw * G::WAVES - 1) / ((int64_t)gxw * G::WAVES);
   const int jb = cb * JT;                              // first row tile of this block (N > 32*JT)
 
-  // k-step boundaries of the segments (static indices: no private-memory copy of the args)
-  int ks_end[WN_MAXSEG];
-  {
-    int acc = 0;
-#pragma unroll
-    for (int s = 0; s < WN_MAXSEG; ++s) {
-      if (s < a.nseg) acc += (a.seg[s].K + 15) >> 4;
-      ks_end[s] = acc;
-    }
-  }
+  // segment boundaries in k-steps; the segment fields themselves are read from the kernel-argument
+  // block by a wave-uniform index (see the resident kernel: local copies would live in scratch)
+  static_assert(WN_MAXSEG == 4, "segment select below is written out for four segments");
+  const int e0 = (a.seg[0].K + 15) >> 4;
+  const int e1 = a.nseg > 1 ? e0 + ((a.seg[1].K + 15) >> 4) : nks_total;
+  const int e2 = a.nseg > 2 ? e1 + ((a.seg[2].K + 15) >> 4) : nks_total;
+  const int plane_ks0 = a.seg[0].plane_k > 0 ? a.seg[0].plane_k / 16 : 0;     // only segment 0 may be planar
+  const int64_t plane_st0 = a.seg[0].plane_stride;
   float wmax = 0.f;
+  unsigned char* const xbuf = reinterpret_cast<unsigned char*>(stage);          // 2 x XBUF_BYTES inside the wave's stage
+  static_assert(2 * G::XBUF_BYTES <= G::STAGE_BYTES, "activation double buffer must fit the output stage");
+  constexpr int PT = G::CHUNK_BYTES / 16 / 512;        // weight-DMA instructions per thread and chunk
+  constexpr int PX = KSC * 2;                          // activation-DMA instructions per lane and chunk
 
   for (int64_t pass = 0; pass < passes; ++pass) {
     const int64_t tile = (pass * gxw + xb) * G::WAVES + wave;
@@ -230,45 +233,40 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
     const int rows_valid = live ? min(32, a.T - t0) : 0;
     const int64_t row0 = (int64_t)b * a.T + t0;
 
-    // per-segment row pointer of this lane (hoisted: the chunk loop then needs no segment fields)
-    const float* xrow_s[WN_MAXSEG];
-    bool xok_s[WN_MAXSEG];
-    const int plane_ks0 = a.seg[0].plane_k > 0 ? a.seg[0].plane_k / 16 : 0;     // only segment 0 may be planar
-    const int64_t plane_st0 = a.seg[0].plane_stride;
+    // Everything the K loop consumes arrives by LDS-DMA: the weight chunk (shared, ring of NBUF buffers)
+    // and this wave's own activations (two buffers inside its otherwise idle output stage; each lane
+    // reads back the 16 bytes it requested).  With no register-destination load in the loop the only
+    // waits are the counted s_waitcnt below: hipcc drains every LDS-DMA (vmcnt(0)) at the first use of
+    // an ordinary load's result while one is in flight.
+    // activations of chunk c -> activation buffer (c & 1); ok[k] = this lane's row is inside the
+    // utterance for k-step k's segment (masked rows / k-steps read a clamped address and are zeroed at use)
+    auto xdma = [&](int c, bool (&okv)[KSC]) {
 #pragma unroll
-    for (int s = 0; s < WN_MAXSEG; ++s) {
-      xrow_s[s] = nullptr;
-      xok_s[s] = false;
-      if (s < a.nseg) {
-        const int ts = t - a.seg[s].shift;
-        xok_s[s] = live && t < a.T && ts >= 0 && ts < a.T;
-        xrow_s[s] = a.seg[s].x + ((int64_t)b * a.T + (xok_s[s] ? ts : 0)) * a.seg[s].ldx + 4 * h;
+      for (int k = 0; k < KSC; ++k) {
+        const int ks_in = c * KSC + k;
+        const int ks = min(ks_in, nks_total - 1);
+        const int si = (ks >= e0) + (ks >= e1) + (ks >= e2);            // wave-uniform segment index
+        const int kk = ks - (si == 0 ? 0 : si == 1 ? e0 : si == 2 ? e1 : e2);
+        const float* bx = a.seg[si].x;
+        const int ld = a.seg[si].ldx, sh = a.seg[si].shift;
+        const int ts = t - sh;
+        const bool ok = live && t < a.T && ts >= 0 && ts < a.T;
+        const float* src = bx + ((int64_t)b * a.T + (ok ? ts : 0)) * ld + 4 * h + 16 * kk;
+        if (plane_ks0 > 0 && si == 0) src += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
+        okv[k] = ok && ks_in < nks_total;
+        unsigned char* dst = xbuf + ((c & 1) * KSC + k) * 2048;          // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8),
+                                         (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
       }
-    }
-    // activations of global k-step ks for this lane: two float4 quads (channels 16kk+4h.., 16kk+8+4h..)
-    // The loads are unconditional (clamped k-step, clamped row; zeroed afterwards): the pipeline below
-    // relies on every chunk issuing the same vector-memory instructions in the same order.
-    auto load_x = [&](int ks_in, f32x4& q0, f32x4& q1, bool& okout) {
-      const int ks = min(ks_in, nks_total - 1);
-      const float* xr = xrow_s[0];
-      bool ok = xok_s[0];
-      int kk = ks;
-#pragma unroll
-      for (int s = 1; s < WN_MAXSEG; ++s)
-        if (ks >= ks_end[s - 1]) { xr = xrow_s[s]; ok = xok_s[s]; kk = ks - ks_end[s - 1]; }   // wave-uniform
-      ok = ok && ks_in < nks_total;
-      if (plane_ks0 > 0 && ks < ks_end[0]) xr += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
-      q0 = wn_ldg4(xr + 16 * kk);
-      q1 = wn_ldg4(xr + 16 * kk + 8);
-      okout = ok;                                      // zeroed where it is consumed, not here (no early wait)
     };
-    // weight chunk c: global -> LDS buffer (c % NBUF) by LDS-DMA (no registers): every wave instruction
-    // moves one contiguous KiB (wave-uniform LDS base + lane * 16).  Blocks past the end of the image
-    // are clamped to a valid block: their activations are zero, so they only need to be finite.
+    // weight chunk c: global -> LDS buffer (c % NBUF): every wave instruction moves one contiguous KiB
+    // (wave-uniform LDS base + lane * 16).  Blocks past the end of the image are clamped to a valid
+    // block: their activations are zero, so they only need to be finite.
     auto wdma = [&](int c) {
-      constexpr int PER_THREAD = G::CHUNK_BYTES / 16 / 512;      // 2 or 4
 #pragma unroll
-      for (int i = 0; i < PER_THREAD; ++i) {
+      for (int i = 0; i < PT; ++i) {
         const int f = tid + 512 * i;                   // 16-byte piece inside the chunk
         const int blk = f >> 7, within = f & 127;
         int ks = c * KSC + blk / JT, j = jb + blk % JT;
@@ -287,32 +285,30 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // Pipeline.  vmcnt retires in order, so the ISSUE ORDER  dma(c), x(c), dma(c+1) | x(c+1), dma(c+2) | ...
-    // makes "x(c) has arrived" imply "dma(c) has arrived" while dma(c+1) and dma(c+2) stay in flight:
-    // touching x(c) before the barrier is the whole synchronisation (the compiler counts the
-    // instructions issued since).  One raw barrier per chunk; a wave can be at most one chunk ahead of
-    // the slowest one, so buffer (c+2) % 4 is never one that is still being read.
-    f32x4 xa[KSC][2], xb[KSC][2];
+    // Issue order  w(0), x(0), w(1) | x(1), w(2) | x(2), w(3) | ...   vmcnt retires in order, so "at most
+    // N outstanding" with N = the requests issued after x(c) -- w(c+1), x(c+1), w(c+2) -- means x(c)
+    // and w(c) have landed while the newer ones stay in flight.  One raw barrier per chunk (for the
+    // other waves' weight pieces); a wave is at most one chunk ahead of the slowest, so buffer
+    // (c + 2) % 4 is never one that is still being read.
     bool oka[KSC], okb[KSC];
-    __syncthreads();                                   // previous pass finished with every buffer
+    __syncthreads();                                   // previous pass finished with the ring and this stage
     wdma(0);
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < KSC; ++k) load_x(k, xa[k][0], xa[k][1], oka[k]);
-    asm volatile("" ::: "memory");
+    xdma(0, oka);
     if (1 < nchunks) wdma(1);
-    asm volatile("" ::: "memory");
-    auto arrive = [&](const f32x4 (&xv)[KSC][2]) {
-      // a use of the LAST activation register of the chunk: the compiler's own s_waitcnt for it covers
-      // every earlier request, including this chunk's weight DMA
-      asm volatile("" ::"v"(xv[KSC - 1][1].w));
+    auto arrive = [&](int c) {
+      if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT + PX) : "memory");
+      else if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT + PX) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
     };
-
-    auto compute = [&](int c, const f32x4 (&xv)[KSC][2], const bool (&okv)[KSC]) {
+    auto compute = [&](int c, const bool (&okv)[KSC]) {
       const h8* wl = reinterpret_cast<const h8*>(smem + (c % G::NBUF) * G::CHUNK_BYTES) + lane;
+      const f32x4* xl = reinterpret_cast<const f32x4*>(xbuf + (c & 1) * G::XBUF_BYTES) + lane;
       // (k-step, tile) blocks in order; the next block's hi|lo fragments are read one block ahead and
       // the schedule is pinned per block so that the compiler does not hoist a whole chunk of LDS reads
+      f32x4 xq[KSC][2];
+#pragma unroll
+      for (int k = 0; k < KSC; ++k) { xq[k][0] = xl[(k * 2 + 0) * 64]; xq[k][1] = xl[(k * 2 + 1) * 64]; }
       h8 fr[2][2];
       fr[0][0] = wl[0];
       fr[0][1] = wl[64];
@@ -324,35 +320,25 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
           fr[(blk + 1) & 1][1] = wl[((blk + 1) * 2 + 1) * 64];
         }
         h8 bh, bl;
-        wn_split8g(xv[k][0], xv[k][1], okv[k] ? sc : 0.f, bh, bl);       // masked rows / k-steps contribute zero
+        wn_split8g(xq[k][0], xq[k][1], okv[k] ? sc : 0.f, bh, bl);       // masked rows / k-steps contribute zero
         acc[j] = wn_mfma16g(fr[blk & 1][1], bh, acc[j]);
         acc[j] = wn_mfma16g(fr[blk & 1][0], bl, acc[j]);
         acc[j] = wn_mfma16g(fr[blk & 1][0], bh, acc[j]);
         __builtin_amdgcn_sched_barrier(0);
       });
+      // this chunk's activation buffer is free again once its LDS reads have returned
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     for (int c = 0; c < nchunks; c += 2) {
-      // ---- even chunk: operands xa; request x(c+1) into xb, then weights of chunk c+2 ----
-      if (c + 1 < nchunks) {
-#pragma unroll
-        for (int k = 0; k < KSC; ++k) load_x((c + 1) * KSC + k, xb[k][0], xb[k][1], okb[k]);
-      }
-      asm volatile("" ::: "memory");
+      if (c + 1 < nchunks) xdma(c + 1, okb);
       if (c + 2 < nchunks) wdma(c + 2);
-      asm volatile("" ::: "memory");
-      arrive(xa);
-      compute(c, xa, oka);
+      arrive(c);
+      compute(c, oka);
       if (c + 1 >= nchunks) break;
-      // ---- odd chunk: operands xb; request x(c+2) into xa, then weights of chunk c+3 ----
-      if (c + 2 < nchunks) {
-#pragma unroll
-        for (int k = 0; k < KSC; ++k) load_x((c + 2) * KSC + k, xa[k][0], xa[k][1], oka[k]);
-      }
-      asm volatile("" ::: "memory");
+      if (c + 2 < nchunks) xdma(c + 2, oka);
       if (c + 3 < nchunks) wdma(c + 3);
-      asm volatile("" ::: "memory");
-      arrive(xb);
-      compute(c + 1, xb, okb);
+      arrive(c + 1);
+      compute(c + 1, okb);
     }
 
     if (live) wn_g16_epilogue<JT, PITCH>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
