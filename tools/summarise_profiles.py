@@ -2,12 +2,13 @@
    <tag>_bench_kernel_stats.csv   (rocprofv3 --kernel-trace --stats of `python bench.py`)
    <tag>_train_pmc_hbm_traffic.csv (separate --pmc FETCH_SIZE / WRITE_SIZE passes, per-launch averages;
                                     FETCH_SIZE doubled: gfx950 reports half of wide coalesced reads)"""
-import collections, csv, glob, shutil, sys
+import collections, csv, glob, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-ks = glob.glob('gpurun_out/final_ks/*/*kernel_stats.csv')
+ks = (glob.glob('gpurun_out/final_ks/*/*kernel_stats.csv') + glob.glob('gpurun_out/final_ks/*kernel_stats.csv'))
 if ks:
-  shutil.copy(ks[0], f'profiles/{tag}_bench_kernel_stats.csv')
+  ks.sort(key=os.path.getmtime)
+  shutil.copy(ks[-1], f'profiles/{tag}_bench_kernel_stats.csv')
 
 
 def agg(path, cname):
@@ -19,8 +20,8 @@ def agg(path, cname):
   return a
 
 
-f = agg('gpurun_out/final_f/*/*counter_collection.csv', 'FETCH_SIZE')
-w = agg('gpurun_out/final_w/*/*counter_collection.csv', 'WRITE_SIZE')
+f = agg('gpurun_out/final_f/*counter_collection.csv', 'FETCH_SIZE')
+w = agg('gpurun_out/final_w/*counter_collection.csv', 'WRITE_SIZE')
 out = ['kernel,calls,FETCH_SIZE_KB_avg_raw,FETCH_bytes_x2_corrected,WRITE_SIZE_KB_avg,WRITE_bytes,total_bytes_corrected']
 for k in f:
   if 'wn_' not in k:

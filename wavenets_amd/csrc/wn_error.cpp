@@ -12,6 +12,18 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 
 // debug / tuning knobs (not part of the reference surface): small integer registers read by the
 // launchers, settable from tools/ scripts without rebuilding
+//    0  fused fp32 block-forward kernel variant / ablations
+//    1  = 1: exact-fp32 MFMA kernels everywhere (no fp16 hi/lo split)
+//    2  = 1: no resident-weights rows GEMM (streamed form instead)
+//    3  = 1: weight gradients alone stay exact fp32
+//    4  = 1: precompute W_s g_skip for all blocks in one contraction (measured slower)
+//    5  = 1: folded-skip weight gradient on the generic job table
+//    6  = 1: queued generation as per-block launches; = 2: fused chain without the skip waves
+//    7  = 1: print the generation workspace map
+//    8  = 1: per-block weight gradients on the generic job table (no wn_wgrad_layer_kernel)
+//    9  = 1: no side stream in the weight-gradient phase
+//   10  > 0: time splits per utterance of the weight-gradient slabs
+//   11  reserved
 static int g_wn_debug[16] = {0};
 int wn_debug_get(int key) { return (key >= 0 && key < 16) ? g_wn_debug[key] : 0; }
 extern "C" int wn_debug_set(int key, int value) {
