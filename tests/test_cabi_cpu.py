@@ -142,4 +142,4 @@ def test_layer_desc_param_count(lib):
   # cfg2 weights/layer: 37 312
   assert lib.wn_layer_param_count(C.byref(d)) == 37312
   assert lib.wn_layer_workspace_floats(C.byref(d), 2, 1000) > 0
-  assert lib.wn_layer_saved_floats(C.byref(d), 2, 1000) >= 2 * 1000 * (128 + 64)
+  assert lib.wn_layer_saved_floats(C.byref(d), 2, 1000) >= 2 * 1000 * (64 + 64)   # sigmoid + gated activation per row
