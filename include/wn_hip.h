@@ -95,8 +95,10 @@ int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t T, int32_t
 int wn_plan_set_dropout(wn_plan* p, float rate, uint64_t seed, uint64_t step);
 uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* test hook */
 
-/* ---- measurement hook (bench.py): HIP events around each residual-block forward launch on
- * the caller's stream; wn_prof_read returns the average per-launch time after a stream sync.
+/* ---- measurement hook (bench.py): HIP events on the caller's stream around the residual-block
+ * forward launches -- one pair around the whole chain when it is N back-to-back launches of the fused
+ * block kernel (a pair per launch would time its own event packets too), else one pair per block;
+ * wn_prof_read returns launches and the average per-launch time after a stream sync.
  * Not part of the reference surface. */
 int wn_debug_set(int key, int value);     /* tuning knobs for tools/ scripts */
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
