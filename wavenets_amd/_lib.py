@@ -12,7 +12,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libwn_hip.so')
+# WN_HIP_LIB: another build of the same library (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get('WN_HIP_LIB') or os.path.join(_HERE, 'libwn_hip.so')
 
 WN_OK, WN_E_INVALID, WN_E_UNSUPPORTED, WN_E_HIP = 0, -1, -2, -3
 ACTIVATIONS = {None: 0, 'linear': 0, 'relu': 1, 'leaky_relu': 2, 'tanh': 3, 'sigmoid': 4, 'elu': 5}

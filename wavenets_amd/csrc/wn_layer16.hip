@@ -46,7 +46,8 @@ struct WnL16 {
   static constexpr int PITCH = CMAX + 4;         // floats; +4 keeps b128 accesses conflict-free
   static constexpr int STAGE_BYTES = 32 * PITCH * 4;
   static constexpr int WAVES = 8;
-  static constexpr int LDS_BYTES = WD_BYTES + WR_BYTES + WAVES * STAGE_BYTES;
+  static constexpr int BIAS_BYTES = (2 * D + R) * 4;          // b_d | b_r, staged once per workgroup
+  static constexpr int LDS_BYTES = WD_BYTES + WR_BYTES + WAVES * STAGE_BYTES + BIAS_BYTES;
 };
 
 // tile (32 rows x C floats) held as D-layout registers -> LDS stage -> coalesced rows in HBM
@@ -95,8 +96,14 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
     f32x4* sr = reinterpret_cast<f32x4*>(smem + G::WD_BYTES);
     for (int i = tid; i < G::WD_BYTES / 16; i += 512) sd[i] = gd[i];
     for (int i = tid; i < G::WR_BYTES / 16; i += 512) sr[i] = gr[i];
+    // the biases too: per tile they would be 6 * (R + D) / 32 global loads whose results are needed at once
+    float* sb = reinterpret_cast<float*>(smem + G::WD_BYTES + G::WR_BYTES + G::WAVES * G::STAGE_BYTES);
+    for (int i = tid; i < 2 * D; i += 512) sb[i] = a.bias_d[i];
+    for (int i = tid; i < R; i += 512) sb[2 * D + i] = a.bias_r[i];
   }
   __syncthreads();
+  const float* lbias_d = reinterpret_cast<const float*>(smem + G::WD_BYTES + G::WR_BYTES + G::WAVES * G::STAGE_BYTES);
+  const float* lbias_r = lbias_d + 2 * D;
   const h8* wd = reinterpret_cast<const h8*>(smem) + lane;                 // block b -> wd[b * 64]
   const h8* wr = reinterpret_cast<const h8*>(smem + G::WD_BYTES) + lane;
   float* stage = reinterpret_cast<float*>(smem + G::WD_BYTES + G::WR_BYTES + wave * G::STAGE_BYTES);
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
     for (int j = 0; j < JU; ++j)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias_d + 32 * j + 8 * rq + 4 * h);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias_d + 32 * j + 8 * rq + 4 * h);
         u[j][4 * rq + 0] = bv.x; u[j][4 * rq + 1] = bv.y; u[j][4 * rq + 2] = bv.z; u[j][4 * rq + 3] = bv.w;
       }
     if (a.cb) {   // wave-uniform
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
     for (int j = 0; j < R32; ++j)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias_r + 32 * j + 8 * rq + 4 * h);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias_r + 32 * j + 8 * rq + 4 * h);
         o[j][4 * rq + 0] = bv.x; o[j][4 * rq + 1] = bv.y; o[j][4 * rq + 2] = bv.z; o[j][4 * rq + 3] = bv.w;
       }
     wn_static_for<KS2>([&](auto sc) {
