@@ -1,6 +1,8 @@
 // Elementwise, loss, sampling and reduction kernels of the WaveNet hot path (gfx950).
 // References: quantiser src/model.py:151-153; mu-law src/utils.py:34-35; inverse
 // src/callbacks.py:126-131; losses src/model.py:505-551; samplers src/model.py:393-503.
+#include <algorithm>
+
 #include "wn_kernels.h"
 
 #define WN_KERAS_EPS 1e-7f
@@ -678,6 +680,79 @@ int wn_launch_dropout(const float* x, const float* g_res, float* out, int64_t n,
   if (n <= 0) return WN_OK;
   hipLaunchKernelGGL(wn_dropout_kernel, dim3(wn_blocks(n)), dim3(256), 0, s, x, g_res, out, n, rate, 1.0f / (1.0f - rate),
                      key, absmax_out);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Global conditioning of ALL residual blocks at once (src/layers.py:116-120,203-204 with the
+// time-invariant condition of src/model.py:221-225: conv_cond(repeat(m)) is a per-utterance bias).
+// The N per-block 1x1 convs are one contraction tmp[B][N*2D] = m . [W_c^1 | ... | W_c^N]; these three
+// kernels move between that layout and the per-block tensors.
+// ---------------------------------------------------------------------------------------------
+// cb[b][u][n] = tmp[u][b*2D + n] + b_c^b[n]
+__global__ void wn_cond_scatter_kernel(const float* tmp, const float* params, int64_t b_off0, int64_t b_stride, int B,
+                                       int N, int D2, float* cb) {
+  const int64_t total = (int64_t)N * B * D2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % D2);
+    const int u = (int)((i / D2) % B);
+    const int b = (int)(i / ((int64_t)D2 * B));
+    cb[i] = tmp[((int64_t)u * N + b) * D2 + n] + params[b_off0 + (int64_t)b * b_stride + n];
+  }
+}
+// dcb[u][b*2D + n] = sum over the time splits of utterance u of the db_d partial sums that the weight
+// gradient kernels left in their slab rows (they ARE the per-utterance column sums of d u)
+__global__ void wn_cond_gather_kernel(const float* slab, int64_t P, int spb, int64_t bd_off0, int64_t bd_stride, int B,
+                                      int N, int D2, float* dcb) {
+  const int64_t total = (int64_t)B * N * D2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % D2);
+    const int b = (int)((i / D2) % N);
+    const int u = (int)(i / ((int64_t)D2 * N));
+    float acc = 0.f;
+    for (int sp = 0; sp < spb; ++sp) acc += slab[(int64_t)(u * spb + sp) * P + bd_off0 + (int64_t)b * bd_stride + n];
+    dcb[i] = acc;
+  }
+}
+// dW_c^b[c][n] = sum_u m[u][c] dcb[u][b*2D + n];  db_c^b[n] = sum_u dcb[u][b*2D + n]
+__global__ void wn_cond_wgrad_kernel(const float* m, const float* dcb, int B, int Cc, int N, int D2, float* grads,
+                                     int64_t w_off0, int64_t w_stride, int64_t b_off0, int64_t b_stride) {
+  const int64_t total = (int64_t)N * (Cc + 1) * D2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % D2);
+    const int c = (int)((i / D2) % (Cc + 1));              // row Cc = the bias
+    const int b = (int)(i / ((int64_t)D2 * (Cc + 1)));
+    float acc = 0.f;
+    for (int u = 0; u < B; ++u) {
+      const float g = dcb[((int64_t)u * N + b) * D2 + n];
+      acc += c < Cc ? m[(int64_t)u * Cc + c] * g : g;
+    }
+    if (c < Cc) grads[w_off0 + (int64_t)b * w_stride + (int64_t)c * D2 + n] = acc;
+    else grads[b_off0 + (int64_t)b * b_stride + n] = acc;
+  }
+}
+int wn_launch_cond_scatter(const float* tmp, const float* params, int64_t b_off0, int64_t b_stride, int B, int N, int D2,
+                           float* cb, hipStream_t s) {
+  const int64_t total = (int64_t)N * B * D2;
+  hipLaunchKernelGGL(wn_cond_scatter_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1024)), dim3(256), 0, s, tmp,
+                     params, b_off0, b_stride, B, N, D2, cb);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+int wn_launch_cond_gather(const float* slab, int64_t P, int spb, int64_t bd_off0, int64_t bd_stride, int B, int N, int D2,
+                          float* dcb, hipStream_t s) {
+  const int64_t total = (int64_t)B * N * D2;
+  hipLaunchKernelGGL(wn_cond_gather_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1024)), dim3(256), 0, s, slab, P,
+                     spb, bd_off0, bd_stride, B, N, D2, dcb);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+int wn_launch_cond_wgrad(const float* m, const float* dcb, int B, int Cc, int N, int D2, float* grads, int64_t w_off0,
+                         int64_t w_stride, int64_t b_off0, int64_t b_stride, hipStream_t s) {
+  const int64_t total = (int64_t)N * (Cc + 1) * D2;
+  hipLaunchKernelGGL(wn_cond_wgrad_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1024)), dim3(256), 0, s, m, dcb, B,
+                     Cc, N, D2, grads, w_off0, w_stride, b_off0, b_stride);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

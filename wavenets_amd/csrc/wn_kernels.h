@@ -178,6 +178,13 @@ uint32_t wn_dropout_key(uint64_t seed, int block, uint64_t step);
 int wn_launch_dropout(const float* x, const float* g_res, float* out, int64_t n, float rate, uint32_t key,
                       float* absmax_out, hipStream_t s);
 int wn_launch_gate(const float* u, int64_t rows, int D, float* ag, float* z, int ldz, hipStream_t s);
+// global conditioning of all blocks at once (wn_elem.hip)
+int wn_launch_cond_scatter(const float* tmp, const float* params, int64_t b_off0, int64_t b_stride, int B, int N, int D2,
+                           float* cb, hipStream_t s);
+int wn_launch_cond_gather(const float* slab, int64_t P, int spb, int64_t bd_off0, int64_t bd_stride, int B, int N, int D2,
+                          float* dcb, hipStream_t s);
+int wn_launch_cond_wgrad(const float* m, const float* dcb, int B, int Cc, int N, int D2, float* grads, int64_t w_off0,
+                         int64_t w_stride, int64_t b_off0, int64_t b_stride, hipStream_t s);
 int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s);
 int64_t wn_colsum_scratch_floats(int B, int C);
 int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, float* scratch, hipStream_t s);

@@ -61,6 +61,9 @@ struct wn_plan {
   std::vector<BlockInfo> blocks;
   std::vector<ConvInfo> finals, mapping;
   int64_t frag_skipF = -1;     // A[Sh][N*Dp] image of the folded skip sum
+  // all blocks' conv_cond as one layer (when every block has one and 2D % 32 == 0): forward image
+  // A[N*2D][Cc], backward image A[Cc][N*2D]; -1 = per-block path
+  int64_t frag_condF = -1, frag_condB = -1;
   int64_t frag16_skipF = -1;   // the same as an fp16 split image, or -1
   int64_t frag16_gzs = -1;     // fp16 split image A[N*D][S]: rows b*D.. = W_s of block b (backward of the folded skip sum)
   int64_t frag_floats = 0;
@@ -237,6 +240,7 @@ struct WsLayout {
   std::vector<int64_t> M;               // mapping activations [B][w]
   int64_t cb;                           // [N][B][2D]
   int64_t dcb, g_m0, g_m1;
+  int64_t cbt;                          // [B][N*2D]: all blocks' conditioning biases / their gradients
   int64_t total;
 };
 
@@ -304,12 +308,13 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     for (size_t j = 0; j < p->mapping.size(); ++j) L.M.push_back(cv.take((int64_t)B * p->mapping[j].cout));
     L.cb = cv.take((int64_t)p->N * B * 2 * p->D);
     L.dcb = cv.take((int64_t)B * 2 * p->D);
+    L.cbt = cv.take((int64_t)B * p->N * 2 * p->D);
     int mw = std::max(p->Cc, p->c.cond_inputs);
     for (auto& m : p->mapping) mw = std::max(mw, m.cout);
     L.g_m0 = cv.take((int64_t)B * mw);
     L.g_m1 = cv.take((int64_t)B * mw);
   } else {
-    L.cb = L.dcb = L.g_m0 = L.g_m1 = 0;
+    L.cb = L.dcb = L.g_m0 = L.g_m1 = L.cbt = 0;
   }
   L.gxd = 0;
   if (training && p->drop_rate > 0.f) {
@@ -775,6 +780,35 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
   }
   for (ConvInfo& cv : p->finals) add_images(p, cv, true, true);
   for (ConvInfo& cv : p->mapping) add_images(p, cv, true, true);
+  {
+    bool all_cond = p->c.cond_inputs > 0 && (2 * p->D) % 32 == 0 && p->N > 0;
+    for (const BlockInfo& bi : p->blocks) all_cond = all_cond && bi.has_cond;
+    if (all_cond) {
+      const int D2 = 2 * p->D;
+      p->frag_condF = p->frag_floats;
+      for (int b = 0; b < p->N; ++b) {
+        WnPrepDesc d;
+        memset(&d, 0, sizeof(d));
+        d.src_off = p->tensors[p->blocks[b].conv_cond.kernel_t].off;
+        d.dst_off = p->frag_condF;
+        d.I = D2; d.KK = p->Cc; d.ld = D2; d.transpose = 1;
+        d.q_off = 0; d.j_off = b * (D2 / 32); d.JT = p->N * (D2 / 32);
+        p->prep.push_back(d);
+      }
+      p->frag_floats += (int64_t)wn_frag_floats(p->N * D2, p->Cc);
+      p->frag_condB = p->frag_floats;
+      for (int b = 0; b < p->N; ++b) {
+        WnPrepDesc d;
+        memset(&d, 0, sizeof(d));
+        d.src_off = p->tensors[p->blocks[b].conv_cond.kernel_t].off;
+        d.dst_off = p->frag_condB;
+        d.I = p->Cc; d.KK = D2; d.ld = D2; d.transpose = 0;
+        d.q_off = b * (D2 / 8); d.j_off = 0; d.JT = ceil32(p->Cc);
+        p->prep.push_back(d);
+      }
+      p->frag_floats += (int64_t)wn_frag_floats(p->Cc, p->N * D2);
+    }
+  }
   // folded skip sum: A[Sh][N*Dp], piece b = (conv_skip or conv1 of block b)^T
   p->frag_skipF = p->frag_floats;
   for (int b = 0; b < p->N; ++b) {
@@ -1029,11 +1063,22 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
       if (rc) return rc;
       m = ws + L.M[j]; mc = c.cout;
     }
+    if (p->frag_condF >= 0) {
+      // all blocks in one contraction, then [B][N*2D] -> [N][B][2D] with the biases added
+      const int D2 = 2 * p->D;
+      const ConvInfo& c0 = p->blocks[0].conv_cond;
+      const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.bias_t].off - p->tensors[c0.bias_t].off : 0;
+      rc = Gemm(1, B, p->N * D2, ceil32(p->N * D2)).seg(m, p->Cc, p->Cc, 0, fragbase + p->frag_condF).run(ws + L.cbt, p->N * D2, s);
+      if (rc) return rc;
+      rc = wn_launch_cond_scatter(ws + L.cbt, params, p->tensors[c0.bias_t].off, bst, B, p->N, D2, ws + L.cb, s);
+      if (rc) return rc;
+    } else {
     for (int b = 0; b < p->N; ++b) {
       const ConvInfo& c = p->blocks[b].conv_cond;
       rc = Gemm(1, B, 2 * p->D, ceil32(2 * p->D)).seg(m, p->Cc, p->Cc, 0, fragbase + c.fragF)
                .bias(params + p->tensors[c.bias_t].off).run(ws + L.cb + (int64_t)b * B * 2 * p->D, 2 * p->D, s);
       if (rc) return rc;
+    }
     }
   }
   // input causal conv, src/model.py:84-88,228 : KS taps with C_in = 1
@@ -1350,6 +1395,9 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         .addc(ws + L.g_m0, p->Cc).run(ws + L.g_m0, p->Cc, s);
   };
 
+  // conditioning of all blocks as one layer: the per-utterance sums of d u come out of the weight-gradient
+  // slab afterwards instead of 2 column-sum launches + 3 tiny products per block (knob 14 = 1: per block)
+  const bool cond_batched = defer && p->frag_condB >= 0 && wn_debug_get(14) != 1;
   if (defer) {
     // ================= data gradients now, every weight gradient in one batched launch =================
     rc = ensure_jobs(p, L, B, T);
@@ -1408,7 +1456,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       bg.g_o_tmp = p->S == 0 ? ws + L.GO[b] : nullptr;
       bg.g_u = ws + L.GU[b];
       bg.g_x = ws + L.GH[b];
-      bg.dcb = bi.has_cond ? ws + L.dcb : nullptr;
+      bg.dcb = (bi.has_cond && !cond_batched) ? ws + L.dcb : nullptr;
       bg.slab = slab;
       bg.am_gxout = bg.g_xout ? am_GH(b + 1) : nullptr;
       bg.am_gskip = g_skip ? am_gskip : nullptr;
@@ -1420,7 +1468,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         // g_o == g_skip for this block: the job table reads GO[b]
         WN_HIP_CHECK(hipMemcpyAsync(ws + L.GO[b], g_skip, rows * p->R * sizeof(float), hipMemcpyDeviceToDevice, s));
       }
-      if (bi.has_cond) {
+      if (bi.has_cond && !cond_batched) {
         rc = cond_block_bwd(bi);
         if (rc) return rc;
       }
@@ -1455,6 +1503,21 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       if (rc) return rc;
     }
     if (fork) WN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0));
+    if (cond_batched) {
+      const int D2 = 2 * p->D;
+      const BlockInfo& b0 = p->blocks[0];
+      const int64_t dst = p->N > 1 ? p->tensors[p->blocks[1].dil[0].bias_t].off - p->tensors[b0.dil[0].bias_t].off : 0;
+      const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.kernel_t].off - p->tensors[b0.conv_cond.kernel_t].off : 0;
+      const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.bias_t].off - p->tensors[b0.conv_cond.bias_t].off : 0;
+      rc = wn_launch_cond_gather(ws + L.bslab, p->nparams, L.bsplits, p->tensors[b0.dil[0].bias_t].off, dst, B, p->N, D2,
+                                 ws + L.cbt, s);
+      if (rc) return rc;
+      rc = Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.cbt, p->N * D2, p->N * D2, 0, fragbase + p->frag_condB).run(ws + L.g_m0, p->Cc, s);
+      if (rc) return rc;
+      rc = wn_launch_cond_wgrad(mlast, ws + L.cbt, B, p->Cc, p->N, D2, grads, p->tensors[b0.conv_cond.kernel_t].off, wst,
+                                p->tensors[b0.conv_cond.bias_t].off, bst, s);
+      if (rc) return rc;
+    }
     rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov, p->ncov, s);
     if (rc) return rc;
     if (!p->c.use_skip && p->S > 0) {
