@@ -214,6 +214,8 @@ MODEL_CASES = {
     'cat_noskipch': dict(blocks=5, channels=32, dilation_bound=16, final_layers_channels=[], bits=8),
     'cat_r64': dict(blocks=4, channels=64, skip_channels=256, dilation_bound=1024, final_layers_channels=[128, 256],
                     activation='leaky_relu', bits=8),
+    'cat_r128': dict(blocks=3, channels=128, skip_channels=64, dilation_bound=8, final_layers_channels=[64],
+                     activation='leaky_relu', bits=8),
     'cat_odd_composed': dict(blocks=4, channels=12, dilation_channels=10, skip_channels=20, dilation_bound=4,
                              final_layers_channels=[9], activation='relu', bits=5),
     'cat_lpb2_odd': dict(blocks=3, layers_per_block=2, kernel_size=3, channels=12, dilation_channels=10, skip_channels=20,

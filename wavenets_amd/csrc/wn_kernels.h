@@ -96,6 +96,16 @@ struct WnWgLayer {
 int wn_wgrad_layer_supported(int R, int D, int KS);
 int wn_launch_wgrad_layers(const WnWgLayer* d_layers, int nlayers, int R, float* ws, float* slab, int64_t P, int B,
                            int T, int splits_per_b, hipStream_t s);
+// one tap of a block's weight gradient as a staged workgroup job (wn_wgrad_pair.hip)
+struct WnWgPair {
+  int64_t x_off, g_off;            // workspace offsets of X [rows][K] and G [rows][N]
+  int64_t w_off, b_off;            // dW[k][n] -> slab row + w_off + k * N + n; db -> slab row + b_off (or < 0)
+  int64_t gmax_off;                // running max-abs of G, or < 0
+  int32_t shift, pad_;             // X row = t - shift
+};
+int wn_wgrad_pair_kind(int K, int N);
+int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
+                          int splits_per_b, hipStream_t s);
 // dW_s / db_s of the folded skip path for all blocks (wn_wgrad_skip.hip)
 int wn_wgrad_skip_supported(int D, int S, int KZ);
 int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64_t rows, int KZ, int S, int D,

@@ -84,6 +84,10 @@ struct wn_plan {
   bool jobs_skipk = false;
   bool jobs_layerk = false;   // per-block dW_d / dW_r come from the layer weight-gradient kernel
   WnWgLayer* d_wgl = nullptr;
+  // per-block weight gradients as staged pair jobs (widths the per-block kernel does not cover), by kind
+  WnWgPair* d_pairs = nullptr;
+  int pair_first[3] = {0, 0, 0}, pair_count[3] = {0, 0, 0};
+  bool jobs_pairk = false;
   // side stream: the low-occupancy generic weight-gradient jobs overlap the per-block / skip kernels
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -886,6 +890,7 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
   if (p->d_wgl) (void)hipFree(p->d_wgl);
+  if (p->d_pairs) (void)hipFree(p->d_pairs);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   if (p->side) (void)hipStreamDestroy(p->side);
@@ -1224,9 +1229,15 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   // knob 8 = 1 keeps the per-block weight gradients on the generic job table
   const bool layerk = wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1 &&
                       wn_debug_get(3) != 1 && wn_debug_get(8) != 1;
+  // knob 13 = 1 keeps them on the generic job table
+  const bool pairk = !layerk && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
+                     wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
+                     wn_debug_get(13) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
-      p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk) return WN_OK;
+      p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
+      p->jobs_pairk == pairk) return WN_OK;
   std::vector<WnWgLayer> wgl;
+  std::vector<WnWgPair> pairs[3];
   std::vector<WnWgJob> jobs;
   std::vector<WnTensorDesc> cov;
   auto cover = [&](int t) { WnTensorDesc d; d.off = p->tensors[t].off; d.len = p->tensors[t].len; cov.push_back(d); };
@@ -1255,6 +1266,23 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       w.gmax_u_off = am_GU(b); w.gmax_h_off = p->S == 0 ? am_skip : am_GH(b + 1);
       w.dilation = c.dil;
       wgl.push_back(w);
+    } else if (pairk) {
+      const int64_t xoff = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
+      for (int t = 0; t < p->KS; ++t) {
+        WnWgPair w;
+        memset(&w, 0, sizeof(w));
+        w.x_off = xoff; w.g_off = L.GU[b]; w.shift = (p->KS - 1 - t) * c.dil;
+        w.w_off = p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D;
+        w.b_off = t == p->KS - 1 ? p->tensors[c.bias_t].off : -1;
+        w.gmax_off = am_GU(b);
+        pairs[1].push_back(w);
+      }
+      WnWgPair w;
+      memset(&w, 0, sizeof(w));
+      w.x_off = zoff; w.g_off = p->S == 0 ? L.GO[b] : L.GH[b + 1]; w.shift = 0;
+      w.w_off = p->tensors[bi.conv1.kernel_t].off; w.b_off = p->tensors[bi.conv1.bias_t].off;
+      w.gmax_off = p->S == 0 ? am_skip : am_GH(b + 1);
+      pairs[2].push_back(w);
     } else {
     for (int t = 0; t < p->KS; ++t)
       add_jobs(jobs, p->drop_rate > 0.f ? L.XD[b] : L.H[b], p->R, p->R, (p->KS - 1 - t) * c.dil, L.GU[b], 2 * p->D, 2 * p->D,
@@ -1291,7 +1319,20 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     WN_HIP_CHECK(hipMalloc((void**)&p->d_wgl, wgl.size() * sizeof(WnWgLayer)));
     WN_HIP_CHECK(hipMemcpy(p->d_wgl, wgl.data(), wgl.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
   }
-  p->jobs_layerk = layerk;
+  if (p->d_pairs) { (void)hipFree(p->d_pairs); p->d_pairs = nullptr; }
+  {
+    std::vector<WnWgPair> all;
+    for (int kd = 1; kd <= 2; ++kd) {
+      p->pair_first[kd] = (int)all.size();
+      p->pair_count[kd] = (int)pairs[kd].size();
+      all.insert(all.end(), pairs[kd].begin(), pairs[kd].end());
+    }
+    if (!all.empty()) {
+      WN_HIP_CHECK(hipMalloc((void**)&p->d_pairs, all.size() * sizeof(WnWgPair)));
+      WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
+    }
+  }
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
   p->jobs_skipk = skipk;
@@ -1476,7 +1517,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     // the generic jobs left over (input conv, head) are few single-wave jobs: they run beside the
     // per-block and skip kernels on a side stream (disjoint slab regions), joined before the reduce.
     // knob 9 = 1 keeps everything on the caller's stream.
-    const bool fork = p->jobs_layerk && wn_debug_get(9) != 1;
+    const bool fork = (p->jobs_layerk || p->jobs_pairk) && wn_debug_get(9) != 1;
     if (fork && !p->side) {
       WN_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
       WN_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
@@ -1489,6 +1530,12 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     rc = wn_launch_wgrad_batched(p->d_jobs, p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, fork ? p->side : s);
     if (rc) return rc;
     if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
+    for (int kd = 1; kd <= 2; ++kd)
+      if (p->jobs_pairk && p->pair_count[kd] > 0) {
+        rc = wn_launch_wgrad_pairs(kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws, ws + L.bslab, p->nparams, B, T,
+                                   L.bsplits, s);
+        if (rc) return rc;
+      }
     if (p->jobs_layerk) {
       rc = wn_launch_wgrad_layers(p->d_wgl, p->N, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
       if (rc) return rc;
