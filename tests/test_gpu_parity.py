@@ -554,3 +554,35 @@ def test_sound_callback_writes_ab_files(tmp_path):
     assert wav.shape == (5, 300, 1) and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
     assert np.load(d / f'generated_spectrogram_{key}.npy').shape == (5, 129, 1, 1)
     assert (d / f'generated_{key}_4.wav').exists()
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases of the tiled kernels: utterances shorter than the dilation (every shifted tap is causal
+# padding), lengths that are not multiples of the 16 / 32 step tiles, a single utterance, and
+# generation batches that do not fill a 32-utterance tile
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,T', [(1, 7), (2, 40), (3, 97)])
+def test_gradients_short_utterances_large_dilations(B, T, math_mode):
+  kw = dict(blocks=9, channels=64, skip_channels=256, dilation_bound=1024, final_layers_channels=[128, 256],
+            activation='leaky_relu', bits=8)             # dilations 1 .. 256: most of them exceed T
+  ocfg, params, model = make_pair(seed=11, **kw)
+  x, _ = _inputs(kw, B, T + 1, seed=12)
+  loss_ref, _, grads_ref, _ = O.loss_and_grads(x.double(), [p.double() for p in params], ocfg)
+  loss, _, _ = model.loss_and_grads(x.to(dev()))
+  assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item()))
+  for n, g, r in zip(model.variable_names, model.gradients(), grads_ref):
+    scale = max(r.abs().max().item(), 1e-6)
+    assert (g.cpu().double() - r).abs().max().item() < 1e-4 * scale + 1e-7, n
+
+
+@pytest.mark.parametrize('B', [33, 70])
+def test_queued_generation_ragged_utterance_tiles(B):
+  kw = dict(MODEL_CASES['cat_r64'])
+  ocfg, params, model = make_pair(seed=7, bias_range=0.3, **kw)
+  w = O.synthetic_waveform(B, model.receptive_field, seed=6).to(dev())
+  naive = model.generate(6, sample=w, use_queues=False, deterministic=True)
+  queued = model.generate(6, sample=w, use_queues=True, deterministic=True)
+  assert torch.equal(naive, queued)
+  # rows are independent: the first utterances do not depend on how many follow
+  few = model.generate(6, sample=w[:5], use_queues=True, deterministic=True)
+  assert torch.equal(few, queued[:5])
