@@ -64,7 +64,9 @@ struct WnG16Pre {
   f32x4 addc[JT][4], aux[JT][4], aux2[JT][4];
 };
 
-template <int JT, int PITCH, int PRE = 0>
+// EPI >= 0 fixes the epilogue kind at compile time (the resident kernels know theirs): the other kinds'
+// code and their live registers disappear
+template <int JT, int PITCH, int PRE = 0, int EPI = -1>
 __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&acc)[JT], float inv_sc, int jb, int b,
                                                 int t, int64_t row0, int rows_valid, float* stage, int lane,
                                                 float& wmax, const WnG16Pre<JT>* pre = nullptr) {
@@ -74,7 +76,8 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
     const int64_t row = row0 + tl;
     const bool tin = t < a.T;
     // GATE_BWD produces two outputs per accumulator; they are staged one after the other
-    const int nout = (a.epi == WN_EPI_GATE_BWD) ? 2 : 1;
+    const int epi = EPI >= 0 ? EPI : a.epi;
+    const int nout = (epi == WN_EPI_GATE_BWD) ? 2 : 1;
     wn_static_for<(JT + 1) / 2>([&](auto gc) {
       constexpr int g2 = decltype(gc)::value;          // pair of row tiles -> 64 channels
       for (int part = 0; part < nout; ++part) {
@@ -103,10 +106,10 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
                 else cv = wn_ldg4(a.addc + row * a.ld_addc + n0);
                 v[0] += cv.x; v[1] += cv.y; v[2] += cv.z; v[3] += cv.w;
               }
-              if (a.epi == WN_EPI_PLAIN) {
+              if (epi == WN_EPI_PLAIN) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], a.act);
-              } else if (a.epi == WN_EPI_DACT) {
+              } else if (epi == WN_EPI_DACT) {
                 f32x4 yv;
                 if constexpr (PRE == 3) yv = pre->aux[j < JT ? j : 0][rq];
                 else yv = wn_ldg4(a.aux + row * a.ld_aux + n0);
@@ -607,7 +610,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
         __builtin_amdgcn_sched_barrier(0);
       });
     }
-    wn_g16_epilogue<JT, PITCH, PREK>(a, acc, inv_sc, 0, cur.b, cur.t, cur.row0, cur.rows_valid, stage, lane, wmax, &pre);
+    constexpr int EPI = PREK == 2 ? WN_EPI_GATE_BWD : (PREK == 1 ? WN_EPI_PLAIN : -1);
+    wn_g16_epilogue<JT, PITCH, PREK, EPI>(a, acc, inv_sc, 0, cur.b, cur.t, cur.row0, cur.rows_valid, stage, lane, wmax, &pre);
     if (has_next) cur = nxt;
   }
   if (absmax_out) {
