@@ -167,7 +167,7 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
   }
 }
 
-template <int JT>
+template <int JT, int EPI>
 __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, const float* w16, int nks_total,
                                                                 const float* absmax_in0, const float* absmax_in1,
                                                                 float* absmax_out) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
       compute(c + 1, okb);
     }
 
-    if (live) wn_g16_epilogue<JT, PITCH>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
+    if (live) wn_g16_epilogue<JT, PITCH, 0, EPI>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
   }
   if (absmax_out) {
 #pragma unroll
@@ -660,10 +660,16 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
     else
       hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 0>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   } else if (jt_need <= 2) {
-    hipLaunchKernelGGL(wn_gemm_rows16_kernel<2>, dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    // the epilogue kind is a template parameter (no dead code of the other kinds in the kernel)
+    if (a.epi == WN_EPI_PLAIN) hipLaunchKernelGGL((wn_gemm_rows16_kernel<2, WN_EPI_PLAIN>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else if (a.epi == WN_EPI_DACT) hipLaunchKernelGGL((wn_gemm_rows16_kernel<2, WN_EPI_DACT>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else hipLaunchKernelGGL((wn_gemm_rows16_kernel<2, WN_EPI_GATE_BWD>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   } else {
     // 128 output channels per workgroup column; wider outputs re-read the activations per column
-    hipLaunchKernelGGL(wn_gemm_rows16_kernel<4>, dim3((unsigned)(gx * ((a.JTtot + 3) / 4)), 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    const dim3 g4((unsigned)(gx * ((a.JTtot + 3) / 4)), 1);
+    if (a.epi == WN_EPI_PLAIN) hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_PLAIN>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else if (a.epi == WN_EPI_DACT) hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_DACT>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_GATE_BWD>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
