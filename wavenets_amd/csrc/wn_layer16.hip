@@ -78,8 +78,16 @@ __device__ __forceinline__ void wn_store_tile(const f32x16 (&v)[C32], float* sta
   asm volatile("" ::: "memory");
 }
 
-template <int R32, int D32, int KS>
-__global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs a) {
+// FAST = the plain training / inference call (taps from x with the block's dilation, no conditioning bias,
+// residual from the newest tap, z written, no separate pre-residual output): the optional paths and
+// their registers are compiled out.  FAST == 2 additionally saves the sigmoid (training).
+template <int R32, int D32, int KS, int FAST>
+__global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs a_in) {
+  WnLayerFwdArgs a = a_in;
+  if constexpr (FAST > 0) {
+    a.xt[0] = a.xt[1] = a.xt[2] = nullptr; a.cb = nullptr; a.res = nullptr; a.o_out = nullptr; a.residual = 1;
+    if constexpr (FAST == 1) a.ag_out = nullptr;
+  }
   using G = WnL16<R32, D32, KS>;
   constexpr int R = G::R, D = G::D, JU = G::JU, KS1 = G::KS1, KS2 = G::KS2, PITCH = G::PITCH;
   constexpr int QR = R / 8;
@@ -257,10 +265,18 @@ int wn_launch_layer_fwd_f16(const WnLayerFwdArgs& a, hipStream_t s) {
   if (tiles <= 0) return WN_OK;
   int64_t gx = (tiles + 7) / 8;
   if (gx > 256) gx = 256;                    // one persistent workgroup per CU
-  if (a.R == 32 && a.KS == 2) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<1, 1, 2>), dim3((unsigned)gx), dim3(512), 0, s, a);
-  else if (a.R == 32 && a.KS == 3) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<1, 1, 3>), dim3((unsigned)gx), dim3(512), 0, s, a);
-  else if (a.R == 64 && a.KS == 2) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<2, 2, 2>), dim3((unsigned)gx), dim3(512), 0, s, a);
+  const bool plain = !a.xt[0] && !a.xt[1] && !a.xt[2] && !a.cb && !a.res && !a.o_out && a.residual && a.z_out;
+  const int fast = (plain && a.ag_out) ? 2 : 0;       // (the inference form, FAST == 1, spills: generic kernel)
+#define WN_L16_LAUNCH(R32_, D32_, KS_)                                                                                      \
+  do {                                                                                                                      \
+    if (fast == 2) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<R32_, D32_, KS_, 2>), dim3((unsigned)gx), dim3(512), 0, s, a);      \
+    else hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<R32_, D32_, KS_, 0>), dim3((unsigned)gx), dim3(512), 0, s, a);                \
+  } while (0)
+  if (a.R == 32 && a.KS == 2) WN_L16_LAUNCH(1, 1, 2);
+  else if (a.R == 32 && a.KS == 3) WN_L16_LAUNCH(1, 1, 3);
+  else if (a.R == 64 && a.KS == 2) WN_L16_LAUNCH(2, 2, 2);
   else { wn_set_error("layer_fwd_f16: unsupported shape R=%d D=%d KS=%d", a.R, a.D, a.KS); return WN_E_UNSUPPORTED; }
+#undef WN_L16_LAUNCH
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
