@@ -30,7 +30,10 @@ struct WnWgSkipArgs {
   const float* gmax;                    // running max-abs of g_skip (operand scaling) or null
 };
 
-template <int NT>   // n tiles (S / 32)
+// NT = n tiles (S / 32); LDZ / LDG = compile-time row strides of Z and g (0: read from the arguments).
+// With static strides the 8 row loads of an operand are one base address + immediate offsets, which
+// frees the registers for a second chunk of look-ahead.
+template <int NT, int LDZ = 0, int LDG = 0>
 __global__ __launch_bounds__(512, 2) void wn_wgrad_skip_kernel(WnWgSkipArgs a) {
   // LDS: two buffers of NT split tiles (hi | lo): NT * 2 KiB each
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 8 * 2048];
@@ -72,12 +75,30 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_skip_kernel(WnWgSkipArgs a) {
   const float* gbase = a.g + ncol;
   auto load = [&](int64_t rr, float (&zv)[8], float (&gv)[8]) {
     const int64_t rb = rr + 8 * h;
+    if constexpr (LDZ > 0 && LDG > 0) {
+      const float* pz = zbase + rb * LDZ;
+      const float* pg = gbase + rb * LDG;
+      if (rr + 16 <= r1) {                               // workgroup-uniform: a full chunk needs no row masks
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int64_t r = rb + e;
-      const bool ok = r < r1;
-      zv[e] = (ok && kok) ? zbase[r * a.ldz] : 0.f;
-      gv[e] = (ok && makes_g) ? gbase[r * a.ldg] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          zv[e] = kok ? pz[e * LDZ] : 0.f;
+          gv[e] = makes_g ? pg[e * LDG] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          zv[e] = (rb + e < r1 && kok) ? pz[e * LDZ] : 0.f;
+          gv[e] = (rb + e < r1 && makes_g) ? pg[e * LDG] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t r = rb + e;
+        const bool ok = r < r1;
+        zv[e] = (ok && kok) ? zbase[r * a.ldz] : 0.f;
+        gv[e] = (ok && makes_g) ? gbase[r * a.ldg] : 0.f;
+      }
     }
   };
   auto split8 = [&](const float (&v)[8], float s, ws_h8& hi, ws_h8& lo) {
@@ -89,63 +110,57 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_skip_kernel(WnWgSkipArgs a) {
     }
   };
 
-  float z0[8], g0[8], z1[8], g1[8];
-  int64_t rr = r0;
   int buf = 0;
-  if (rr < r1) load(rr, z0, g0);
-  for (; rr < r1; rr += 32) {
-    // ---- chunk A (rows rr .. rr+15): operands z0/g0; prefetch chunk B ----
-    if (rr + 16 < r1) load(rr + 16, z1, g1);
-    {
-      ws_h8 zh, zl, gh, gl;
-      split8(z0, 1.0f, zh, zl);
-      if (makes_g) {
+  auto compute = [&](const float (&zv)[8], const float (&gv)[8]) {
+    ws_h8 zh, zl, gh, gl;
+    split8(zv, 1.0f, zh, zl);
+    if (makes_g) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bsum += g0[e];
-        split8(g0, gsc, gh, gl);
-        ws_h8* dst = reinterpret_cast<ws_h8*>(smem + buf * (8 * 2048) + wave * 2048);
-        dst[lane] = gh;
-        dst[64 + lane] = gl;
-      }
-      __syncthreads();
-      const ws_h8* src = reinterpret_cast<const ws_h8*>(smem + buf * (8 * 2048));
-      if (wave_has_k) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const ws_h8 bh = src[j * 128 + lane], bl = src[j * 128 + 64 + lane];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zl, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, bl, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, bh, acc[j], 0, 0, 0);
-        }
-      }
-      buf ^= 1;
+      for (int e = 0; e < 8; ++e) bsum += gv[e];
+      split8(gv, gsc, gh, gl);
+      ws_h8* dst = reinterpret_cast<ws_h8*>(smem + buf * (8 * 2048) + wave * 2048);
+      dst[lane] = gh;
+      dst[64 + lane] = gl;
     }
-    if (rr + 16 >= r1) break;
-    // ---- chunk B: operands z1/g1; prefetch the next chunk A ----
-    if (rr + 32 < r1) load(rr + 32, z0, g0);
-    {
-      ws_h8 zh, zl, gh, gl;
-      split8(z1, 1.0f, zh, zl);
-      if (makes_g) {
+    __syncthreads();
+    const ws_h8* src = reinterpret_cast<const ws_h8*>(smem + buf * (8 * 2048));
+    if (wave_has_k) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bsum += g1[e];
-        split8(g1, gsc, gh, gl);
-        ws_h8* dst = reinterpret_cast<ws_h8*>(smem + buf * (8 * 2048) + wave * 2048);
-        dst[lane] = gh;
-        dst[64 + lane] = gl;
+      for (int j = 0; j < NT; ++j) {
+        const ws_h8 bh = src[j * 128 + lane], bl = src[j * 128 + 64 + lane];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zl, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, bh, acc[j], 0, 0, 0);
       }
-      __syncthreads();
-      const ws_h8* src = reinterpret_cast<const ws_h8*>(smem + buf * (8 * 2048));
-      if (wave_has_k) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const ws_h8 bh = src[j * 128 + lane], bl = src[j * 128 + 64 + lane];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zl, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, bl, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zh, bh, acc[j], 0, 0, 0);
-        }
-      }
-      buf ^= 1;
+    }
+    buf ^= 1;
+  };
+  if constexpr (LDZ > 0 && LDG > 0) {
+    // three register sets: the raw operands of the next TWO chunks are in flight during a chunk's MFMAs
+    float zr[3][8], gr[3][8];
+    int64_t rr = r0;
+    if (rr < r1) load(rr, zr[0], gr[0]);
+    if (rr + 16 < r1) load(rr + 16, zr[1], gr[1]);
+    for (; rr < r1; rr += 48) {
+      if (rr + 32 < r1) load(rr + 32, zr[2], gr[2]);
+      compute(zr[0], gr[0]);
+      if (rr + 16 >= r1) break;
+      if (rr + 48 < r1) load(rr + 48, zr[0], gr[0]);
+      compute(zr[1], gr[1]);
+      if (rr + 32 >= r1) break;
+      if (rr + 64 < r1) load(rr + 64, zr[1], gr[1]);
+      compute(zr[2], gr[2]);
+    }
+  } else {
+    float z0[8], g0[8], z1[8], g1[8];
+    int64_t rr = r0;
+    if (rr < r1) load(rr, z0, g0);
+    for (; rr < r1; rr += 32) {
+      if (rr + 16 < r1) load(rr + 16, z1, g1);
+      compute(z0, g0);
+      if (rr + 16 >= r1) break;
+      if (rr + 32 < r1) load(rr + 32, z0, g0);
+      compute(z1, g1);
     }
   }
 
@@ -188,7 +203,10 @@ int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64
     case 5: hipLaunchKernelGGL(wn_wgrad_skip_kernel<5>, grid, dim3(512), 0, s, a); break;
     case 6: hipLaunchKernelGGL(wn_wgrad_skip_kernel<6>, grid, dim3(512), 0, s, a); break;
     case 7: hipLaunchKernelGGL(wn_wgrad_skip_kernel<7>, grid, dim3(512), 0, s, a); break;
-    default: hipLaunchKernelGGL(wn_wgrad_skip_kernel<8>, grid, dim3(512), 0, s, a); break;
+    default:
+      if (ldz == 64 && ldg == 256) hipLaunchKernelGGL((wn_wgrad_skip_kernel<8, 64, 256>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL(wn_wgrad_skip_kernel<8>, grid, dim3(512), 0, s, a);
+      break;
   }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
