@@ -1189,7 +1189,8 @@ int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float
   const int64_t rows = (int64_t)B * T;
   const float gscale = 1.0f / (float)global_batch;     // compute_average_loss, src/model.py:328-329
   int rc;
-  float* g_logits = want_grad ? ws + L.g_a : nullptr;
+  // deferred weight gradients read d loss / d logits from GF.back(): written there directly (no 131 MB copy)
+  float* g_logits = want_grad ? ((deferred_wgrad(p) && !L.GF.empty()) ? ws + L.GF.back() : ws + L.g_a) : nullptr;
   if (p->c.head == WN_HEAD_CATEGORICAL) {
     rc = wn_launch_quantize(ws + L.yt, reinterpret_cast<int32_t*>(ws + L.target), rows, p->c.bits, s);
     if (rc) return rc;
@@ -1443,8 +1444,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     // ================= data gradients now, every weight gradient in one batched launch =================
     rc = ensure_jobs(p, L, B, T);
     if (rc) return rc;
-    // the loss stage wrote d loss / d logits to g_a: the last final layer's g lives in GF.back()
-    WN_HIP_CHECK(hipMemcpyAsync(ws + L.GF.back(), ws + L.g_a, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // (the loss stage wrote d loss / d logits straight into GF.back(), the last final layer's g)
     float* head_out = p->c.use_skip ? ws + L.g_skipsum : ws + L.GH[p->N];
     for (int i = (int)p->finals.size() - 1; i >= 0; --i) {
       const ConvInfo& c = p->finals[i];
