@@ -193,6 +193,37 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
       wsk[ks][1] = wsi[(blk + 1) * 64];
     }
   };
+  // When skip waves exist they issue ALL of block b's LDS-DMA (they are idle most of a block) and publish
+  // it at barrier (3) of block b - 1; the chain waves then neither issue nor wait.  The KiB chunks of a
+  // block are a flat list: gated-conv fragments | conv1 fragments | u0 image | one bias copy per conv1 wave.
+  const int nskip = (int)(blockDim.x >> 6) - JU;
+  const bool dma_by_skip = nskip > 0;
+  auto dma_shared = [&](int b, const WnGenBlock& nb) {
+    unsigned char* buf = smem + (b & 1) * HALF;
+    constexpr int NWD = KSR * JU * 2, NWR = KS2 * R32 * 2, NU0 = JU * 4;
+    const f32x4* wd = reinterpret_cast<const f32x4*>(a.ws + nb.w16d_off) + (int64_t)KS0 * JU * 128 + lane;
+    const f32x4* wr = reinterpret_cast<const f32x4*>(a.ws + nb.w16r_off) + lane;
+    const f32x4* u0 = reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + ((int64_t)b * gridDim.x + tile) * (JU * 4) * 64 + lane;
+    for (int op = sw; op < NWD + NWR + NU0 + R32; op += nskip) {          // wave-uniform
+      if (op < NWD) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wd + op * 64),
+                                         (__attribute__((address_space(3))) void*)(buf + op * 1024), 16, 0, 0);
+      } else if (op < NWD + NWR) {
+        const int c = op - NWD;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wr + c * 64),
+                                         (__attribute__((address_space(3))) void*)(buf + S::WD_BYTES + c * 1024), 16, 0, 0);
+      } else if (op < NWD + NWR + NU0) {
+        const int c = op - NWD - NWR;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(u0 + c * 64),
+                                         (__attribute__((address_space(3))) void*)(buf + U0_OFF + c * 1024), 16, 0, 0);
+      } else {
+        const int c = op - NWD - NWR - NU0;
+        const float* br = a.params + nb.bias_r_off + min(lane, R - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)br,
+                                         (__attribute__((address_space(3))) void*)(buf + BR_OFF + c * 256), 4, 0, 0);
+      }
+    }
+  };
   // tile of fp32 values (this lane's 16 accumulators = two k-steps) -> hi|lo B operands of k-steps 2j, 2j+1
   auto put_xop = [&](const f32x16& x, int j) {
 #pragma unroll
@@ -213,8 +244,13 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
   f32x16 carry;
 #pragma unroll
   for (int r = 0; r < 16; ++r) carry[r] = 0.f;
-  if (is_chain) dma(0, cur);
-  else pre_skip(0);
+  if (is_chain) {
+    if (!dma_by_skip) dma(0, cur);
+  } else {
+    dma_shared(0, cur);
+    pre_skip(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block 0's LDS image is complete at the barrier below
+  }
 
   // ---- input causal conv (C_in = 1): the k-ordered fma chain of the fp32 MFMA path, then + bias ----
   if (is_conv1) {
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
       // everything requested at the top of the previous block (block b's fragments, u0, bias; the
       // stores) is complete.  All of this wave's global traffic is issued HERE, one block before it
       // is needed, so this wait never sees a fresh request.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!dma_by_skip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (live) {
         if (b > 0) {
           float* zdst = a.ws + a.zrow_off + ((int64_t)(b - 1) * a.B + utt) * D + 16 * wave + 4 * h;
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
             *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{carry[4 * rq + 0], carry[4 * rq + 1], carry[4 * rq + 2], carry[4 * rq + 3]};
         }
       }
-      if (b + 1 < nblocks) dma(b + 1, nxt);
+      if (b + 1 < nblocks && !dma_by_skip) dma(b + 1, nxt);
       asm volatile("" ::: "memory");
       // ---- phase A: u tile `wave` = u0 + W_{k-1}^T x ----
       f32x16 u;
@@ -280,6 +316,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
     }
+    if (!is_chain && b + 1 < nblocks) dma_shared(b + 1, nxt);    // the other LDS half is free since barrier (3) of b - 1
     GN_BARRIER();                                     // (1) u tiles visible
     if (is_chain) {
       // ---- phase B: z k-step `wave` = channels 16 * wave + {4h.., 8 + 4h..} ----
@@ -333,7 +370,12 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
         carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bl, carry, 0, 0, 0);
         carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bh, carry, 0, 0, 0);
       }
-      if (b + 1 < nblocks) pre_skip(b + 1);
+      // block b + 1's LDS image must be complete before barrier (3); the skip fragments requested after it
+      // (2 KS2 loads, vmcnt retires in order) may stay in flight
+      if (b + 1 < nblocks) {
+        pre_skip(b + 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS2) : "memory");
+      }
     }
     cur = nxt;
     nxt = nn;
