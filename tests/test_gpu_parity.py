@@ -586,3 +586,15 @@ def test_queued_generation_ragged_utterance_tiles(B):
   # rows are independent: the first utterances do not depend on how many follow
   few = model.generate(6, sample=w[:5], use_queues=True, deterministic=True)
   assert torch.equal(few, queued[:5])
+
+
+@pytest.mark.parametrize('skip_channels', [32, 96, 160])
+def test_queued_generation_skip_wave_counts(skip_channels):
+  """1, 3 and 5 skip waves in the fused generation chain (they also issue the chain's LDS-DMA)."""
+  kw = dict(blocks=5, channels=32, skip_channels=skip_channels, dilation_bound=8, final_layers_channels=[64],
+            activation='leaky_relu', num_mixtures=4, sampling_function='logistic', bits=16)
+  ocfg, params, model = make_pair(seed=9, bias_range=0.3, **kw)
+  w = O.synthetic_waveform(4, model.receptive_field, seed=3).to(dev())
+  naive = model.generate(12, sample=w, use_queues=False, deterministic=True)
+  queued = model.generate(12, sample=w, use_queues=True, deterministic=True)
+  assert torch.equal(naive, queued)          # continuous (mixture) outputs: equality is bit for bit
