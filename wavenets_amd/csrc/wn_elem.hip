@@ -192,6 +192,66 @@ __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, c
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* l = logits + row * C;
+  if (C <= 256) {
+    // the row lives in registers (element k of a lane = class lane + 64 k, the same assignment and the
+    // same per-lane summation order as the general path below): one read of the logits, one exp per class
+    float v[4], e[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = lane + 64 * k;
+      v[k] = j < C ? l[j] : -INFINITY;
+      m = fmaxf(m, v[k]);
+    }
+    m = wn_wave_max(m);
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k] = lane + 64 * k < C ? expf(v[k] - m) : 0.f;
+      if (lane + 64 * k < C) z += e[k];
+    }
+    z = wn_wave_sum(z);
+    const float inv = 1.0f / z;
+    float S = 0.f, A = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < C) {
+        const float q = e[k] * inv;
+        S += fminf(fmaxf(q, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+        if (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) A += q;
+      }
+    S = wn_wave_sum(S);
+    A = wn_wave_sum(A);
+    int tgt = target[row];
+    tgt = tgt < 0 ? 0 : (tgt >= C ? C - 1 : tgt);
+    const float qt = expf(l[tgt] - m) * inv;
+    const float pt = fminf(fmaxf(qt, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+    const float ct = (qt >= WN_KERAS_EPS && qt <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+    if (lane == 0) loss_rows[row] = -(logf(pt) - logf(S));
+    if (g_logits) {
+      float gmax = 0.f;
+      const float invS = 1.0f / S;
+      const float dot = A * invS - ct * qt / pt;     // sum_j g_j q_j
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        if (j < C) {
+          const float q = e[k] * inv;
+          const float c = (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+          float g = c * invS;
+          if (j == tgt) g -= ct / pt;
+          const float gl = gscale * q * (g - dot);
+          g_logits[row * C + j] = gl;
+          gmax = fmaxf(gmax, fabsf(gl));
+        }
+      }
+      if (absmax_out) {
+        gmax = wn_wave_max(gmax);
+        if (lane == 0) wn_absmax_publish(absmax_out, gmax);
+      }
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int j = lane; j < C; j += 64) m = fmaxf(m, l[j]);
   m = wn_wave_max(m);
