@@ -125,6 +125,40 @@ def main():
   _lib.check(L.wn_prof_read(model._plan, C.byref(n_l), C.byref(avg_ms)))
   _lib.check(L.wn_prof_enable(model._plan, 0))
 
+  # where the step goes (untimed extra steps): phase marks inside wn_train_fwd_bwd (HIP events on the launch
+  # stream) + torch events around the gradient all-reduce and the optimizer
+  phases = None
+  from wavenets_amd import dp as _dp
+  if rank == 0:
+    _lib.check(L.wn_phase_enable(model._plan, 1))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = [0.0] * 6
+    nph = 3
+    for _ in range(nph):
+      ev[0].record()
+      loss_p, _, _ = model.loss_and_grads(x)
+      ev[1].record()
+      _dp.allreduce_gradients(model.flat_grads, loss_p)      # no-op for a single replica
+      ev[2].record()
+      model.optimizer.apply_gradients(model)
+      ev[3].record()
+      torch.cuda.synchronize()
+      ms4 = (C.c_float * 4)()
+      _lib.check(L.wn_phase_read(model._plan, ms4))
+      for i in range(4):
+        acc[i] += ms4[i]
+      acc[4] += ev[1].elapsed_time(ev[2])
+      acc[5] += ev[2].elapsed_time(ev[3])
+    _lib.check(L.wn_phase_enable(model._plan, 0))
+    names = ['forward', 'loss', 'backward_data', 'weight_gradients', 'allreduce', 'optimizer']
+    phases = {n: round(a / nph, 4) for n, a in zip(names, acc)}
+  elif world > 1:                                         # the other ranks take part in the collectives
+    for _ in range(3):
+      loss_p, _, _ = model.loss_and_grads(x)
+      _dp.allreduce_gradients(model.flat_grads, loss_p)
+      model.optimizer.apply_gradients(model)
+  sync()
+
   # the same step with the exact-fp32 MFMA kernels (debug knob 1), reported beside the default
   L.wn_debug_set(1, 1)
   model.train_step(x)
@@ -168,6 +202,7 @@ def main():
         'math': 'fp32 tensors; contractions as fp16 hi/lo split, 3 products on v_mfma_f32_32x32x16_f16 with fp32 '
                 'accumulate (|err| <= 6e-7 on O(1) results, parity-tested at 1e-4); exact-fp32 MFMA selectable',
         'exact_fp32_mfma': {'ms_per_step': dt_fp32 * 1e3, 'value': world * B * T / dt_fp32},
+        'phases_ms': phases,
         'config': {'workload': 'configs[1]: 30-layer (3x10) mu-law-256 WaveNet, 64 residual / 256 skip ch, '
                                f'head [128,256], batch {B}x{T} per GPU, full train step '
                                '(fwd+loss+bwd+allreduce+clipnorm-Adam)',

@@ -103,6 +103,10 @@ uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* t
 int wn_debug_set(int key, int value);     /* tuning knobs for tools/ scripts */
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
 int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
+/* phase marks of wn_train_fwd_bwd: ms4 = {forward, loss, backward-data chain, weight gradients + rest}
+ * of the last call (read after a stream sync) */
+int wn_phase_enable(wn_plan* p, int32_t on);
+int wn_phase_read(wn_plan* p, float* ms4);
 
 /* ---- WaveNet.call, src/model.py:213-239 ----
  * x (B,T,1); cond (B, cond_inputs) or NULL; out (B,T,C_out): probabilities (categorical) or

@@ -96,6 +96,8 @@ struct wn_plan {
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   std::vector<int> prof_cnt;         // launches between the events of pair i
+  hipEvent_t phase_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // wn_phase_enable: train-step phase marks
+  bool phase_on = false;
   int prof_used = 0;
   bool prof_on = false;
 };
@@ -887,6 +889,7 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_tdesc) (void)hipFree(p->d_tdesc);
   if (p->d_kdesc) (void)hipFree(p->d_kdesc);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->phase_ev) if (e) (void)hipEventDestroy(e);
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
   if (p->d_wgl) (void)hipFree(p->d_wgl);
@@ -922,6 +925,20 @@ extern "C" int wn_prof_enable(wn_plan* p, int32_t max_launches) {
     WN_HIP_CHECK(hipEventCreate(&e));
     p->prof_ev.push_back(e);
   }
+  return WN_OK;
+}
+// ---- phase marks of wn_train_fwd_bwd (bench.py): events after the forward, the loss, the backward-data
+//      chain and at the end; wn_phase_read returns the four durations of the LAST call in milliseconds ----
+extern "C" int wn_phase_enable(wn_plan* p, int32_t on) {
+  if (!p) return WN_E_INVALID;
+  if (on && !p->phase_ev[0])
+    for (hipEvent_t& e : p->phase_ev) WN_HIP_CHECK(hipEventCreate(&e));
+  p->phase_on = on != 0;
+  return WN_OK;
+}
+extern "C" int wn_phase_read(wn_plan* p, float* ms4) {
+  if (!p || !ms4 || !p->phase_ev[0]) return WN_E_INVALID;
+  for (int i = 0; i < 4; ++i) WN_HIP_CHECK(hipEventElapsedTime(ms4 + i, p->phase_ev[i], p->phase_ev[i + 1]));
   return WN_OK;
 }
 // average milliseconds per recorded launch (call after the stream has been synchronised)
@@ -1399,8 +1416,10 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   float* inputs = ws + L.probs;
   hipLaunchKernelGGL(wn_shift_split_kernel, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 4096)), dim3(256), 0, s,
                      x_full, B, T, inputs, ws + L.yt);
+  if (p->phase_on) (void)hipEventRecord(p->phase_ev[0], s);
   int rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
   if (rc) return rc;
+  if (p->phase_on) (void)hipEventRecord(p->phase_ev[1], s);
   // running max-abs scalars of the gradient tensors (operand scaling of the split-precision GEMMs)
   float* am = ws + L.absmax;
   const int nf = (int)p->finals.size();
@@ -1416,6 +1435,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     else rc = hipMemcpyAsync(pred_out, ws + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
     if (rc) return rc;
   }
+  if (p->phase_on) (void)hipEventRecord(p->phase_ev[2], s);
   const float* fragbase = ws + L.frag;
   float* slab = ws + L.slab;
 
@@ -1514,6 +1534,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         if (rc) return rc;
       }
     }
+    if (p->phase_on) (void)hipEventRecord(p->phase_ev[3], s);      // backward-data chain done
     // the generic jobs left over (input conv, head) are few single-wave jobs: they run beside the
     // per-block and skip kernels on a side stream (disjoint slab regions), joined before the reduce.
     // knob 9 = 1 keeps everything on the caller's stream.
@@ -1670,6 +1691,10 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   } else {
     rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
     if (rc) return rc;
+  }
+  if (p->phase_on) {
+    if (!defer) (void)hipEventRecord(p->phase_ev[3], s);             // per-call weight gradients: no separate phase
+    (void)hipEventRecord(p->phase_ev[4], s);
   }
   return WN_OK;
 }
