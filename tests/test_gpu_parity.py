@@ -598,3 +598,14 @@ def test_queued_generation_skip_wave_counts(skip_channels):
   naive = model.generate(12, sample=w, use_queues=False, deterministic=True)
   queued = model.generate(12, sample=w, use_queues=True, deterministic=True)
   assert torch.equal(naive, queued)          # continuous (mixture) outputs: equality is bit for bit
+
+
+def test_queued_generation_ring_wraparound():
+  """More steps than the deepest ring has slots (dilation 32 -> 33 slots): every ring wraps at least twice."""
+  kw = dict(blocks=6, channels=32, skip_channels=64, dilation_bound=64, final_layers_channels=[32],
+            activation='leaky_relu', bits=8)
+  ocfg, params, model = make_pair(seed=5, bias_range=0.3, **kw)
+  w = O.synthetic_waveform(2, model.receptive_field, seed=8).to(dev())
+  naive = model.generate(80, sample=w, use_queues=False, deterministic=True)
+  queued = model.generate(80, sample=w, use_queues=True, deterministic=True)
+  assert torch.equal(naive, queued)
