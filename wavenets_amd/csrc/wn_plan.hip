@@ -1512,7 +1512,11 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         bg.drop_rate = p->drop_rate; bg.drop_key = wn_dropout_key(p->drop_seed, b, p->drop_step); bg.g_xd = ws + L.gxd;
       }
       // the last block's output gradient is identically zero when the head reads the skip sum
-      bg.g_xout = (p->c.use_skip && b == p->N - 1) ? nullptr : ws + L.GH[b + 1];
+      // (with the skip head nothing flows into the last block's output: GH[N] was zero-filled above.  It is
+      //  still passed as a gradient -- unless S == 0, where g_o is assembled from g_skip alone -- so that
+      //  the last block runs the same split-precision kernels as the others instead of the fp32 fallback
+      //  for the one-segment product)
+      bg.g_xout = (p->c.use_skip && b == p->N - 1 && (p->S == 0 || wn_debug_get(15) == 1)) ? nullptr : ws + L.GH[b + 1];
       bg.g_skip = g_skip;
       bg.g_o_tmp = p->S == 0 ? ws + L.GO[b] : nullptr;
       bg.g_u = ws + L.GU[b];
