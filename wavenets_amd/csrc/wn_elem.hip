@@ -584,8 +584,16 @@ __global__ void wn_sumsq_kernel(const float* g, const WnTensorDesc* table, float
   __shared__ double sm[256];
   const WnTensorDesc d = table[blockIdx.x];
   const float* p = g + d.off;
-  double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < d.len; i += blockDim.x) acc += (double)p[i] * (double)p[i];
+  // four independent chains: a single one ran at one memory round trip per element (63 us for 1.25 M values)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int64_t i = threadIdx.x;
+  for (; i + 3 * 256 < d.len; i += 4 * 256) {
+    const float v0 = p[i], v1 = p[i + 256], v2 = p[i + 512], v3 = p[i + 768];
+    a0 += (double)v0 * (double)v0; a1 += (double)v1 * (double)v1;
+    a2 += (double)v2 * (double)v2; a3 += (double)v3 * (double)v3;
+  }
+  for (; i < d.len; i += 256) a0 += (double)p[i] * (double)p[i];
+  const double acc = (a0 + a1) + (a2 + a3);
   sm[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
