@@ -824,3 +824,35 @@ int wn_launch_cond_wgrad(const float* m, const float* dcb, int B, int Cc, int N,
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
+
+// Input causal conv (C_in = 1, src/model.py:84-88,228): y[b][t][c] = b[c] + sum_tap w[tap][c] x[b][t-(KS-1-tap)].
+// Arithmetic = the k-ordered fma chain from zero, then + bias: what the fp32 MFMA product it replaces
+// computed and what the generation chain kernel (wn_gen.hip) reproduces, so all three agree bit for bit.
+__global__ __launch_bounds__(256) void wn_inconv_fwd_kernel(const float* x, const float* w, const float* bias, int B, int T,
+                                                            int R, int KS, float* y) {
+  const int q = R / 4;                                   // float4 groups per row
+  const int64_t total = (int64_t)B * T * q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % q) * 4;
+    const int64_t row = i / q;
+    const int t = (int)(row % T);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int tap = 0; tap < KS; ++tap) {
+      const int ts = t - (KS - 1 - tap);
+      const float xv = ts >= 0 ? x[row - (KS - 1 - tap)] : 0.f;
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)tap * R + c);
+      a0 = fmaf(wv.x, xv, a0); a1 = fmaf(wv.y, xv, a1); a2 = fmaf(wv.z, xv, a2); a3 = fmaf(wv.w, xv, a3);
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+    *reinterpret_cast<f32x4*>(y + row * R + c) = f32x4{a0 + bv.x, a1 + bv.y, a2 + bv.z, a3 + bv.w};
+  }
+}
+int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int B, int T, int R, int KS, float* y,
+                         hipStream_t s) {
+  const int64_t total = (int64_t)B * T * (R / 4);
+  if (total <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_inconv_fwd_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, x, w, bias,
+                     B, T, R, KS, y);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

@@ -1105,10 +1105,16 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   }
   // input causal conv, src/model.py:84-88,228 : KS taps with C_in = 1
   {
-    Gemm g(B, T, p->R, ceil32(p->R));
-    for (int t = 0; t < p->KS; ++t)
-      g.seg(x, 1, 1, (p->KS - 1 - t), fragbase + p->causal.fragF + t * p->causal.fragF_stride);
-    rc = g.bias(params + p->tensors[p->causal.bias_t].off).run(ws + L.H[0], p->R, s);
+    if (p->R % 4 == 0 && wn_debug_get(1) != 1) {
+      // elementwise kernel, same fma chain as the matrix product below computes for a K = 1 operand
+      rc = wn_launch_inconv_fwd(x, params + p->tensors[p->causal.kernel_t].off, params + p->tensors[p->causal.bias_t].off, B, T,
+                                p->R, p->KS, ws + L.H[0], s);
+    } else {
+      Gemm g(B, T, p->R, ceil32(p->R));
+      for (int t = 0; t < p->KS; ++t)
+        g.seg(x, 1, 1, (p->KS - 1 - t), fragbase + p->causal.fragF + t * p->causal.fragF_stride);
+      rc = g.bias(params + p->tensors[p->causal.bias_t].off).run(ws + L.H[0], p->R, s);
+    }
     if (rc) return rc;
     if (rings) {
       rc = ring_capture(x, B, T, 1, p->KS, rings->xin, s);
