@@ -856,3 +856,46 @@ int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int 
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
+
+// Queued generation, categorical head, deterministic: softmax -> arg max -> sample value -> output row and
+// next network input, in ONE launch.  The arithmetic per row is that of wn_softmax_kernel followed by
+// wn_sample_det_cat_kernel (same lane assignment, same reductions), so the result is the same sample.
+__global__ __launch_bounds__(256) void wn_gen_tail_cat_det_kernel(const float* logits, int rows, int C, float inv_lv,
+                                                                  float* out, int length, int step, float* xin_slot) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* l = logits + (int64_t)row * C;
+  float m = -INFINITY;
+  for (int j = lane; j < C; j += 64) m = fmaxf(m, l[j]);
+  m = wn_wave_max(m);
+  float z = 0.f;
+  for (int j = lane; j < C; j += 64) z += expf(l[j] - m);
+  z = wn_wave_sum(z);
+  const float inv = 1.0f / z;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < C; j += 64) {
+    const float v = expf(l[j] - m) * inv;        // the probability wn_softmax_kernel would have stored
+    if (v > best) { best = v; bi = j; }          // strictly greater keeps the first maximum
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    const float sv = (float)bi * inv_lv - 1.0f;
+    out[(int64_t)row * length + step] = sv;
+    if (xin_slot) xin_slot[row] = sv;
+  }
+}
+int wn_launch_gen_tail_cat_det(const float* logits, int rows, int C, int bits, float* out, int length, int step,
+                               float* xin_slot, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_gen_tail_cat_det_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, rows, C,
+                     1.0f / (float)(1 << (bits - 1)), out, length, step, xin_slot);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

@@ -197,6 +197,8 @@ int wn_launch_cond_wgrad(const float* m, const float* dcb, int B, int Cc, int N,
                          int64_t w_stride, int64_t b_off0, int64_t b_stride, hipStream_t s);
 int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int B, int T, int R, int KS, float* y,
                          hipStream_t s);
+int wn_launch_gen_tail_cat_det(const float* logits, int rows, int C, int bits, float* out, int length, int step,
+                               float* xin_slot, hipStream_t s);
 int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s);
 int64_t wn_colsum_scratch_floats(int B, int C);
 int wn_launch_colsum_per_batch(const float* g, int B, int T, int C, float* out, float* scratch, hipStream_t s);

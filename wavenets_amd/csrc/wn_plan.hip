@@ -2009,11 +2009,17 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       if (rc) return rc;
       hin = dst; hc = c.cout;
     }
-    rc = sample_rows(p, last, B, deterministic != 0, seed, (uint64_t)step, lastp, samp, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(wn_gen_emit_kernel, dim3((B + 255) / 256), dim3(256), 0, s, samp, B, out, length, step,
-                       R.xin + (int64_t)((tau + 1) % p->KS) * B);
-    WN_HIP_CHECK(hipGetLastError());
+    if (p->c.head == WN_HEAD_CATEGORICAL && deterministic && wn_debug_get(6) != 3) {
+      // softmax + arg max + emit in one launch (knob 6 = 3: the three separate kernels)
+      rc = wn_launch_gen_tail_cat_det(last, B, p->Cout, p->c.bits, out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B, s);
+      if (rc) return rc;
+    } else {
+      rc = sample_rows(p, last, B, deterministic != 0, seed, (uint64_t)step, lastp, samp, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(wn_gen_emit_kernel, dim3((B + 255) / 256), dim3(256), 0, s, samp, B, out, length, step,
+                         R.xin + (int64_t)((tau + 1) % p->KS) * B);
+      WN_HIP_CHECK(hipGetLastError());
+    }
   }
   return WN_OK;
 }
