@@ -609,3 +609,22 @@ def test_queued_generation_ring_wraparound():
   naive = model.generate(80, sample=w, use_queues=False, deterministic=True)
   queued = model.generate(80, sample=w, use_queues=True, deterministic=True)
   assert torch.equal(naive, queued)
+
+
+def test_plan_caches_survive_shape_changes():
+  """One model object through training and generation at changing batch sizes / lengths: the plan's
+  cached device tables (weight-gradient jobs, generation block table) are keyed by shape."""
+  from wavenets_amd import Adam
+  kw = dict(MODEL_CASES['cat_r64'])
+  ocfg, params, model = make_pair(seed=3, bias_range=0.2, **kw)
+  model.compile(optimizer=Adam(learning_rate=1e-3, clipnorm=1.0))
+  losses = []
+  for B, T in ((2, 200), (3, 97), (2, 200)):
+    x = O.synthetic_waveform(B, T + 1, seed=B * 100 + T).to(dev())
+    losses.append(model.train_step(x)['loss'])
+    for gb in (3, 5):
+      w = O.synthetic_waveform(gb, model.receptive_field, seed=gb).to(dev())
+      a = model.generate(5, sample=w, use_queues=True, deterministic=True)
+      b = model.generate(5, sample=w, use_queues=False, deterministic=True)
+      assert torch.equal(a, b)
+  assert all(math.isfinite(v) for v in losses)
