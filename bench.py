@@ -79,7 +79,7 @@ def main():
   import torch
   import torch.distributed as dist
   from wavenets_amd import WaveNet, Adam, _lib
-  from oracle import wavenet_oracle as O     # synthetic input generator + cpu_baseline leg only
+  from wavenets_amd.data import synthetic_waveforms    # (oracle/ is imported by the cpu_baseline leg only)
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -103,7 +103,7 @@ def main():
   B, T = args.batch, args.length
   model = WaveNet(**CFG2, device=dev, seed=0)          # glorot kernels, zero biases, same on all ranks
   model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
-  x = O.synthetic_waveform(B, T + 1, seed=1234 + rank).to(dev)
+  x = synthetic_waveforms(B, T + 1, seed=1234 + rank, device=dev)
 
   def sync():
     if world > 1:
