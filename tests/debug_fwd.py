@@ -1,7 +1,8 @@
-"""Debug: forward of small model cases vs the oracle under debug knobs."""
+"""Debug helper (not a test; it lives here because only tests/ may use the oracle): forward of a small
+model case vs the oracle under debug knobs:  python tests/debug_fwd.py <case> [KEY VAL ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from wavenets_amd import _lib
 import test_gpu_parity as T

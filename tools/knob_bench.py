@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from wavenets_amd import WaveNet, Adam, _lib
-from oracle import wavenet_oracle as O
+from wavenets_amd.data import synthetic_waveforms
 L = _lib.lib()
 args = [int(a) for a in sys.argv[1:]]
 for k, v in zip(args[0::2], args[1::2]):
@@ -12,7 +12,7 @@ for k, v in zip(args[0::2], args[1::2]):
 dev = torch.device('cuda', 0)
 m = WaveNet(**bench.CFG2, device=dev)
 m.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
-x = O.synthetic_waveform(8, 16001, seed=1).to(dev)
+x = synthetic_waveforms(8, 16001, seed=1, device=dev)
 for _ in range(4):
   m.train_step(x)
 torch.cuda.synchronize()
