@@ -19,7 +19,7 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //    4  = 1: precompute W_s g_skip for all blocks in one contraction (measured slower)
 //    5  = 1: folded-skip weight gradient on the generic job table
 //    6  = 1: queued generation as per-block launches; = 2: fused chain without the skip waves;
-//       = 3: softmax / arg max / emit as three launches
+//       = 3: softmax / arg max / emit as three launches; = 4: one launch per head layer
 //    7  = 1: print the generation workspace map
 //    8  = 1: per-block weight gradients on the generic job table (no wn_wgrad_layer_kernel)
 //    9  = 1: no side stream in the weight-gradient phase

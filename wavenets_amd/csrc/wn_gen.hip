@@ -406,6 +406,117 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
   }
 }
 
+// The head of a queued-generation step -- up to WN_GEN_HEAD_MAX 1x1 convs with bias and activation
+// (src/model.py:105-119,237-238) -- for 32 utterances per workgroup in ONE launch instead of one launch
+// per layer.  Wave w owns column tile w of the current layer (all layers here have at most 8 tiles); a
+// layer's activated output is turned into fp16 hi | lo B operands (k-step = 16 channels) and handed to
+// the next layer through LDS, exactly as the chain kernel hands x between blocks.  Per tile this is the
+// thin rows GEMM's sequence -- k-steps in order, lo*hi, hi*lo, hi*hi, then acc + bias, activation -- so
+// the logits are bit-identical to the per-layer launches (and to the sliding window).
+__global__ __launch_bounds__(512) void wn_gen_head_kernel(WnGenHeadArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16 * 2048];       // two operand buffers of 16 k-steps
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tl = lane & 31, h = lane >> 5;
+  const int utt = blockIdx.x * 32 + tl;
+  const bool live = utt < a.B;
+  const int ur = live ? utt : 0;
+  // ---- input rows -> operand buffer 0: wave w converts k-steps w, w + 8 ----
+  {
+    const float* row = a.ws + a.in_off + (int64_t)ur * a.in_ld + 4 * h;
+    const int nks = a.K[0] / 16;
+    for (int ks = wave; ks < nks; ks += 8) {
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(row + 16 * ks);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(row + 16 * ks + 8);
+      gn_h8 bh, bl;
+      gn_split8(q0, q1, bh, bl);
+      gn_h8* dst = reinterpret_cast<gn_h8*>(smem + ks * 2048) + lane;
+      dst[0] = bh;
+      dst[64] = bl;
+    }
+  }
+  __syncthreads();
+  for (int li = 0; li < a.nlayers; ++li) {
+    const int nks = a.K[li] / 16, nt = a.N[li] / 32;
+    const unsigned char* ib = smem + (li & 1) * (16 * 2048);
+    unsigned char* ob = smem + ((li + 1) & 1) * (16 * 2048);
+    const bool lastl = li + 1 == a.nlayers;
+    if (wave < nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const gn_h8* wimg = reinterpret_cast<const gn_h8*>(a.ws + a.w16_off[li]) + lane;
+      const gn_h8* xl = reinterpret_cast<const gn_h8*>(ib) + lane;
+      // weight fragments four k-steps ahead (register ring, static slots)
+      gn_h8 wf[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t blk = ((int64_t)min(i, nks - 1) * nt + wave) * 2;
+        wf[i][0] = wimg[(blk + 0) * 64];
+        wf[i][1] = wimg[(blk + 1) * 64];
+      }
+      for (int ks0 = 0; ks0 < nks; ks0 += 4) {
+        wn_static_for<4>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if (ks0 + i < nks) {                          // wave-uniform
+            const gn_h8 bh = xl[((ks0 + i) * 2 + 0) * 64];
+            const gn_h8 bl = xl[((ks0 + i) * 2 + 1) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][1], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], bh, acc, 0, 0, 0);
+            const int64_t blk = ((int64_t)min(ks0 + i + 4, nks - 1) * nt + wave) * 2;
+            wf[i][0] = wimg[(blk + 0) * 64];
+            wf[i][1] = wimg[(blk + 1) * 64];
+          }
+        });
+      }
+      // epilogue of the rows GEMM: acc (* 1) + bias, activation
+      const float* bias = a.params + a.bias_off[li] + 32 * wave + 4 * h;
+      float v[16];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 8 * rq);
+        v[4 * rq + 0] = wn_act(acc[4 * rq + 0] + bv.x, a.act[li]);
+        v[4 * rq + 1] = wn_act(acc[4 * rq + 1] + bv.y, a.act[li]);
+        v[4 * rq + 2] = wn_act(acc[4 * rq + 2] + bv.z, a.act[li]);
+        v[4 * rq + 3] = wn_act(acc[4 * rq + 3] + bv.w, a.act[li]);
+      }
+      if (lastl) {
+        if (live) {
+          float* dst = a.ws + a.out_off + (int64_t)utt * a.N[li] + 32 * wave + 4 * h;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{v[4 * rq + 0], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
+        }
+      } else {
+        // this tile = k-steps 2 wave, 2 wave + 1 of the next layer
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4 q0 = {v[8 * hf + 0], v[8 * hf + 1], v[8 * hf + 2], v[8 * hf + 3]};
+          const f32x4 q1 = {v[8 * hf + 4], v[8 * hf + 5], v[8 * hf + 6], v[8 * hf + 7]};
+          gn_h8 bh, bl;
+          gn_split8(q0, q1, bh, bl);
+          gn_h8* dst = reinterpret_cast<gn_h8*>(ob + (2 * wave + hf) * 2048) + lane;
+          dst[0] = bh;
+          dst[64] = bl;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s) {
+  if (a.nlayers < 1 || a.nlayers > WN_GEN_HEAD_MAX) { wn_set_error("gen_head: bad layer count"); return WN_E_UNSUPPORTED; }
+  for (int i = 0; i < a.nlayers; ++i)
+    if (a.K[i] % 16 != 0 || a.K[i] > 256 || a.N[i] % 32 != 0 || a.N[i] > 256 || (i > 0 && a.K[i] != a.N[i - 1])) {
+      wn_set_error("gen_head: unsupported layer shape");
+      return WN_E_UNSUPPORTED;
+    }
+  hipLaunchKernelGGL(wn_gen_head_kernel, dim3((unsigned)((a.B + 31) / 32)), dim3(512), 0, s, a);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
 int wn_gen_blocks_supported(int R, int D, int KS) {
   if (R == 32 && D == 32) return KS == 2 || KS == 3;
   if (R == 64 && D == 64) return KS == 2;

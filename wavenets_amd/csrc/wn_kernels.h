@@ -175,6 +175,19 @@ struct WnGenStepArgs {
   int64_t tau;
   int32_t B, nblocks, residual;
 };
+// the head of a generation step in one launch (wn_gen.hip)
+#define WN_GEN_HEAD_MAX 4
+struct WnGenHeadArgs {
+  const float* params;
+  float* ws;
+  int64_t in_off;                  // [B][in_ld] input rows (folded skip sum or last block output)
+  int64_t out_off;                 // [B][N[last]] logits
+  int64_t w16_off[WN_GEN_HEAD_MAX];   // fp16 split images A[N][K] (workspace offsets)
+  int64_t bias_off[WN_GEN_HEAD_MAX];  // parameter offsets
+  int32_t K[WN_GEN_HEAD_MAX], N[WN_GEN_HEAD_MAX], act[WN_GEN_HEAD_MAX];
+  int32_t in_ld, nlayers, B, pad_;
+};
+int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s);
 int wn_gen_blocks_supported(int R, int D, int KS);
 int64_t wn_gen_u0_floats(int B, int nblocks, int D);
 int wn_gen_skip_fusable(int S);

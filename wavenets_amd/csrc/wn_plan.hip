@@ -1999,6 +1999,26 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       hin = workspace + G.hrow0;
     }
     int hc = p->Hin;
+    // the whole head in one launch when every layer is one the split-precision rows GEMM would take
+    // (knob 6 = 4: one launch per layer)
+    bool head_fused = fused_step && wn_debug_get(6) != 4 && !p->finals.empty() && (int)p->finals.size() <= WN_GEN_HEAD_MAX &&
+                      p->Hin % 16 == 0 && p->Hin <= 256;
+    for (const ConvInfo& c : p->finals)
+      head_fused = head_fused && c.frag16 >= 0 && c.cout % 32 == 0 && c.cout >= 64 && c.cout <= 256 && c.cin % 16 == 0 && c.cin <= 256;
+    if (head_fused) {
+      WnGenHeadArgs ha;
+      memset(&ha, 0, sizeof(ha));
+      ha.params = params; ha.ws = workspace; ha.in_off = hin - workspace; ha.in_ld = p->Hin; ha.out_off = G.last;
+      ha.nlayers = (int)p->finals.size(); ha.B = B;
+      for (size_t i = 0; i < p->finals.size(); ++i) {
+        const ConvInfo& c = p->finals[i];
+        ha.w16_off[i] = G.prime + L.frag + c.frag16; ha.bias_off[i] = p->tensors[c.bias_t].off;
+        ha.K[i] = c.cin; ha.N[i] = c.cout;
+        ha.act[i] = (i + 1 == p->finals.size()) ? WN_ACT_LINEAR : p->c.activation;
+      }
+      rc = wn_launch_gen_head(ha, s);
+      if (rc) return rc;
+    } else {
     for (size_t i = 0; i < p->finals.size(); ++i) {
       const ConvInfo& c = p->finals[i];
       const bool lastl = (i + 1 == p->finals.size());
@@ -2008,6 +2028,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
                .bias(params + p->tensors[c.bias_t].off).act(lastl ? WN_ACT_LINEAR : p->c.activation).run(dst, c.cout, s);
       if (rc) return rc;
       hin = dst; hc = c.cout;
+    }
     }
     if (p->c.head == WN_HEAD_CATEGORICAL && deterministic && wn_debug_get(6) != 3) {
       // softmax + arg max + emit in one launch (knob 6 = 3: the three separate kernels)
