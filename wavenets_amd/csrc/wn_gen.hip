@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64) void wn_gen_pre_kernel(WnGenStepArgs a) {
   f32x4 xq[KS - 1][QR];
 #pragma unroll
   for (int t = 0; t + 1 < KS; ++t) {
-    const int64_t slot = (a.tau - (int64_t)(KS - 1 - t) * blk.dilation) % blk.nslots;
+    // 32-bit index arithmetic (the host checks nslots * B * R < 2^31): a 64-bit modulo is ~100 instructions
+    const int slot = (int)((unsigned)((int)a.tau - (KS - 1 - t) * blk.dilation) % (unsigned)blk.nslots);
     const float* src = ring + (slot * a.B + ur) * R + 4 * h;
 #pragma unroll
     for (int q = 0; q < QR; ++q) xq[t][q] = *reinterpret_cast<const f32x4*>(src + 8 * q);
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
   if (is_conv1) {
     float xs[KS];
 #pragma unroll
-    for (int t = 0; t < KS; ++t) xs[t] = a.xin[(int64_t)((a.tau - (KS - 1 - t)) % KS) * a.B + ur];
+    for (int t = 0; t < KS; ++t) xs[t] = a.xin[(int)((unsigned)((int)a.tau - (KS - 1 - t)) % (unsigned)KS) * a.B + ur];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = 32 * wave + wn_drow(r, h);
@@ -280,12 +281,12 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
       if (!dma_by_skip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (live) {
         if (b > 0) {
-          float* zdst = a.ws + a.zrow_off + ((int64_t)(b - 1) * a.B + utt) * D + 16 * wave + 4 * h;
+          float* zdst = a.ws + a.zrow_off + ((b - 1) * a.B + utt) * D + 16 * wave + 4 * h;
           *reinterpret_cast<f32x4*>(zdst) = z0;
           *reinterpret_cast<f32x4*>(zdst + 8) = z1;
         }
         if (is_conv1) {                               // this block's input at time tau -> its ring
-          float* dst = a.ws + cur.ring_off + ((int64_t)(a.tau % cur.nslots) * a.B + utt) * R + 32 * wave + 4 * h;
+          float* dst = a.ws + cur.ring_off + ((int)((unsigned)(int)a.tau % (unsigned)cur.nslots) * a.B + utt) * R + 32 * wave + 4 * h;
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq)
             *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{carry[4 * rq + 0], carry[4 * rq + 1], carry[4 * rq + 2], carry[4 * rq + 3]};

@@ -1895,7 +1895,10 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   float* Zrow = workspace + G.Zrow;
   // fused step kernel (input conv + every block in one launch) when the split-precision block kernel
   // is the one the sliding window uses; otherwise the blocks run as separate launches
-  const bool fused_step = p->fused16_ok && p->LPB == 1 && wn_debug_get(1) != 1 && wn_debug_get(6) != 1 &&
+  // (the fused kernels index rings and rows with 32-bit arithmetic)
+  const bool fits32 = (int64_t)(RF + 1) * B * std::max(p->R, p->D) < (1LL << 31) && (int64_t)RF + length < (1LL << 31) &&
+                      (int64_t)p->N * B * p->D < (1LL << 31);
+  const bool fused_step = p->fused16_ok && p->LPB == 1 && wn_debug_get(1) != 1 && wn_debug_get(6) != 1 && fits32 &&
                           wn_gen_blocks_supported(p->R, p->D, p->KS);
   const bool skip_in_chain = fused_step && p->c.use_skip && p->frag16_skipF >= 0 && wn_gen_skip_fusable(p->Sh) &&
                              wn_debug_get(6) != 2;   // knob 6 = 2: skip contraction as its own launch
