@@ -228,6 +228,9 @@ MODEL_CASES = {
                              use_residual=False, final_layers_channels=[16], activation='elu', bits=6),
     'mol': dict(blocks=4, channels=32, skip_channels=64, dilation_bound=8, final_layers_channels=[32],
                 activation='leaky_relu', num_mixtures=10, sampling_function='logistic', bits=16),
+    'mol_r128_k3': dict(blocks=5, kernel_size=3, channels=128, skip_channels=96, dilation_bound=81,
+                        final_layers_channels=[64], activation='leaky_relu', num_mixtures=3,
+                        sampling_function='logistic', bits=16),
     'gauss': dict(blocks=4, channels=32, skip_channels=64, dilation_bound=8, final_layers_channels=[32],
                   activation='leaky_relu', num_mixtures=8, sampling_function='gaussian', bits=16),
     'cond': dict(blocks=4, channels=32, skip_channels=64, dilation_bound=8, final_layers_channels=[32],
@@ -463,7 +466,8 @@ def test_generate_errors():
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('name,det', [('cat_noskipch', True), ('cat_small_fused', True), ('cat_r64', True),
                                       ('mol', True), ('cond', True), ('cat_odd_composed', True),
-                                      ('cat_k3', True), ('cat_noskip_nores', True), ('cat_small_fused', False)])
+                                      ('cat_k3', True), ('cat_noskip_nores', True), ('cat_small_fused', False),
+                                      ('cat_r128', True)])
 def test_queued_generation_equals_naive(name, det):
   kw = dict(MODEL_CASES[name])
   ocfg, params, model = make_pair(seed=7, bias_range=0.3, **kw)
@@ -477,6 +481,31 @@ def test_queued_generation_equals_naive(name, det):
   queued = model.generate(n, condition=cond, sample=w, use_queues=True, deterministic=det)
   assert queued.shape == (B, n, 1)
   assert torch.equal(naive, queued), (naive - queued).abs().max()
+
+
+def test_queued_generation_kernel_size_3_keeps_full_history():
+  """kernel_size = 3: the reference's receptive_field (src/model.py:122, 1 + sum(d) (k - 1) + 1) is k - 2
+  samples shorter than the network's true reach (sum(d) (k - 1) + k), so its sliding window zero-pads one
+  sample the ring buffers still hold.  The sliding window here reproduces the reference (truncated window);
+  the queued sampler is the untruncated recurrence.  Both are checked against the oracle."""
+  kw = dict(MODEL_CASES['mol_r128_k3'])
+  ocfg, params, model = make_pair(seed=7, bias_range=0.3, **kw)
+  rf = O.receptive_field(ocfg)
+  assert model.receptive_field == rf and (rf - 2) % 2 == 0      # 1 + sum(d) (k - 1) + 1
+  w = O.synthetic_waveform(2, rf, seed=4)
+  n = 6
+  naive = model.generate(n, sample=w.to(dev()), use_queues=False, deterministic=True)
+  assert (naive.cpu() - O.generate_naive(params, ocfg, n, w)).abs().max() < 1e-4
+  queued = model.generate(n, sample=w.to(dev()), use_queues=True, deterministic=True)
+  x = w.clone()
+  full = []
+  with torch.no_grad():
+    for _ in range(n):                                   # growing sequence: nothing is dropped on the left
+      pred = O.model_forward(x, params, ocfg)[:, -1:, :]
+      full.append(O.sample_waveform_deterministic(pred, ocfg))
+      x = torch.cat([x, full[-1].to(x.dtype)], dim=1)
+  assert (queued.cpu() - torch.cat(full, dim=1)).abs().max() < 1e-4
+  assert torch.equal(queued[:, 0], naive[:, 0])          # the first sample sees the same window
 
 
 def test_queued_generation_with_stacked_dilated_convs():
@@ -628,3 +657,37 @@ def test_plan_caches_survive_shape_changes():
       b = model.generate(5, sample=w, use_queues=False, deterministic=True)
       assert torch.equal(a, b)
   assert all(math.isfinite(v) for v in losses)
+
+
+@pytest.mark.parametrize('B,T', [(1, 20), (3, 97)])
+def test_wide_blocks_gradients_ragged(B, T, math_mode):
+  """128-channel blocks (BASELINE configs[3] width): the forward is two split-precision contractions with the
+  gate in the first one's epilogue (fp32 mode: the exact one-kernel forward).  Utterances shorter than the
+  larger dilations and lengths off the 32-step tile."""
+  kw = dict(blocks=7, channels=128, skip_channels=256, dilation_bound=128, final_layers_channels=[128, 256],
+            activation='leaky_relu', num_mixtures=10, sampling_function='logistic', bits=16)
+  ocfg, params, model = make_pair(seed=13, **kw)
+  x, _ = _inputs(kw, B, T + 1, seed=14)
+  loss_ref, _, grads_ref, _ = O.loss_and_grads(x.double(), [p.double() for p in params], ocfg)
+  loss, _, _ = model.loss_and_grads(x.to(dev()))
+  assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item()))
+  for n, g, r in zip(model.variable_names, model.gradients(), grads_ref):
+    scale = max(r.abs().max().item(), 1e-6)
+    assert (g.cpu().double() - r).abs().max().item() < 1e-4 * scale + 1e-7, n
+
+
+def test_wide_blocks_forward_paths_agree():
+  """The composed split-precision forward of 128-channel blocks against the exact-fp32 one-kernel forward
+  (debug knob 11) on the same weights: activations within the 1e-4 bar at a length with many tiles."""
+  from wavenets_amd import _lib
+  kw = dict(MODEL_CASES['cat_r128'])
+  ocfg, params, model = make_pair(seed=21, **kw)
+  x = O.synthetic_waveform(2, 4100, seed=22).to(dev())
+  try:
+    _lib.lib().wn_debug_set(11, 1)
+    ref = model.logits(x).clone()
+  finally:
+    _lib.lib().wn_debug_set(11, 0)
+  out = model.logits(x)
+  assert not torch.equal(out, ref)                        # two different kernels really ran
+  assert (out - ref).abs().max().item() < ATOL_ACT

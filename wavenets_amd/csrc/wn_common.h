@@ -22,6 +22,7 @@ enum WnEpilogue : int {
   WN_EPI_PLAIN = 0,      // y = act(acc + bias + rowbias + addc)
   WN_EPI_DACT = 1,       // y = (acc + addc) * act'(saved y)        (backward data)
   WN_EPI_GATE_BWD = 2,   // acc is dL/dz; y[:, :D] = dL/du_f, y[:, D:] = dL/du_g from saved (a, g)
+  WN_EPI_GATE_FWD = 3,   // acc is u = [filter | gate] (column blocks of 64 + 64): y = tanh * sigmoid, y2 = sigmoid
 };
 
 __device__ __forceinline__ f32x16 wn_mfma(float a, float b, f32x16 c) {

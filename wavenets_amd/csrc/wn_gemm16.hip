@@ -71,6 +71,57 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
                                                 int t, int64_t row0, int rows_valid, float* stage, int lane,
                                                 float& wmax, const WnG16Pre<JT>* pre = nullptr) {
   const int tl = lane & 31, h = lane >> 5;
+  if constexpr (EPI == WN_EPI_GATE_FWD) {
+    // Forward gate of a residual block whose weights do not fit LDS (R = D = 128): the image's row tiles
+    // are ordered [f f g g] per 128-column block, so this workgroup holds filter channels
+    // c0 .. c0 + 63 (tiles 0, 1) and their gate channels (tiles 2, 3) and can gate locally.
+    static_assert(JT == 4, "gate-forward epilogue needs [f f g g] column blocks");
+    const int D = a.N / 2;
+    const int c0 = 16 * jb;                              // jb = 4 * column block -> 64 output channels per block
+    const bool tin = t < a.T;
+    for (int part = 0; part < (a.y2 ? 2 : 1); ++part) {
+      f32x16 outv[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int n = c0 + 32 * jj + 8 * rq + 4 * h;   // channel inside [0, D)
+          float z[4] = {0.f, 0.f, 0.f, 0.f};
+          if (tin) {
+            const f32x4 bf = wn_ldg4(a.bias + n), bg = wn_ldg4(a.bias + D + n);
+            const float bfv[4] = {bf.x, bf.y, bf.z, bf.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f = acc[jj][4 * rq + e] * inv_sc + bfv[e];
+              const float g = acc[jj + 2][4 * rq + e] * inv_sc + bgv[e];
+              const float sg = wn_sigmoid_fast(g);
+              z[e] = part == 0 ? wn_tanh_fast(f) * sg : sg;
+            }
+          }
+          outv[jj][4 * rq + 0] = z[0]; outv[jj][4 * rq + 1] = z[1]; outv[jj][4 * rq + 2] = z[2]; outv[jj][4 * rq + 3] = z[3];
+        }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          f32x4 o;
+          o.x = outv[jj][4 * rq + 0]; o.y = outv[jj][4 * rq + 1]; o.z = outv[jj][4 * rq + 2]; o.w = outv[jj][4 * rq + 3];
+          *reinterpret_cast<f32x4*>(stage + tl * PITCH + 32 * jj + 8 * rq + 4 * h) = o;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float* dst = (part == 0 ? a.y + row0 * a.ldy : a.y2 + row0 * a.ld_y2) + c0;
+      const int64_t ldd = part == 0 ? a.ldy : a.ld_y2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = i * 4 + (lane >> 4);
+        const int col = (lane & 15) * 4;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(stage + r * PITCH + col);
+        if (r < rows_valid) *reinterpret_cast<f32x4*>(dst + (int64_t)r * ldd + col) = o;
+      }
+      asm volatile("" ::: "memory");
+    }
+    return;
+  }
   {
     // ---- epilogue in registers (D layout), then staged row stores, 64 channels at a time ----
     const int64_t row = row0 + tl;
@@ -642,8 +693,9 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   int64_t gx = (tiles + 7) / 8;
   if (gx > 256) gx = 256;
   const int jt_need = (a.N + 31) / 32;
+  if (a.epi == WN_EPI_GATE_FWD && (jt_need % 4 != 0 || !a.bias)) { wn_set_error("gemm_rows16: gate-forward epilogue needs 128-column blocks and a bias"); return WN_E_UNSUPPORTED; }
   // few rows (queued generation): one wave per (row tile, column tile), see the thin kernel
-  if (tiles * jt_need <= 64 && tiles <= 8) {
+  if (tiles * jt_need <= 64 && tiles <= 8 && a.epi != WN_EPI_GATE_FWD) {
     hipLaunchKernelGGL(wn_gemm_rows16_thin_kernel<8>, dim3((unsigned)tiles, (unsigned)jt_need), dim3(64), 0, s, a, w16, nks,
                        absmax_in0, absmax_in1, absmax_out);
     WN_HIP_CHECK(hipGetLastError());
@@ -667,7 +719,8 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   } else {
     // 128 output channels per workgroup column; wider outputs re-read the activations per column
     const dim3 g4((unsigned)(gx * ((a.JTtot + 3) / 4)), 1);
-    if (a.epi == WN_EPI_PLAIN) hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_PLAIN>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    if (a.epi == WN_EPI_GATE_FWD) hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_GATE_FWD>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else if (a.epi == WN_EPI_PLAIN) hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_PLAIN>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
     else if (a.epi == WN_EPI_DACT) hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_DACT>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
     else hipLaunchKernelGGL((wn_gemm_rows16_kernel<4, WN_EPI_GATE_BWD>), g4, dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
   }

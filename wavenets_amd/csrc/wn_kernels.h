@@ -59,6 +59,8 @@ struct WnGemmArgs {
   float* y;
   int32_t ldy;
   int32_t vec_out;        // 1: y/addc/aux rows 16-byte aligned, N % 4 == 0
+  float* y2;              // WN_EPI_GATE_FWD: the sigmoid [rows][ld_y2], or null (inference)
+  int32_t ld_y2;
 };
 int wn_launch_gemm_rows(const WnGemmArgs& a, hipStream_t s);
 // split-precision variant: w16 = ONE fp16 hi|lo image of all segments' weights concatenated along k

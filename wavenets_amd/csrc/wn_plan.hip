@@ -47,6 +47,7 @@ struct BlockInfo {
   bool has_skip = false, has_cond = false;
   int64_t g16u = -1;    // fp16 split image [W_r | W_s] (backward: d z) or -1
   int64_t g16r = -1;    // fp16 split image [W_r] alone (used with the precomputed W_s g_skip slice) or -1
+  int64_t f16gate = -1; // fp16 split image of the gated conv with row tiles ordered [f f g g] per 64 channels, or -1
 };
 
 }  // namespace
@@ -416,6 +417,7 @@ struct Gemm {
     a.epi = WN_EPI_GATE_BWD; a.aux = g; a.ld_aux = ldg; a.aux2 = z; a.ld_aux2 = ldz;
     return *this;
   }
+  Gemm& gate_fwd(float* sig, int ld) { a.epi = WN_EPI_GATE_FWD; a.y2 = sig; a.ld_y2 = ld; return *this; }
   int run(float* y, int ldy, hipStream_t s) {
     a.y = y; a.ldy = ldy;
     bool v = (a.N % 4 == 0) && (ldy % 4 == 0) && al16(y);
@@ -423,9 +425,11 @@ struct Gemm {
     if (a.addc) v = v && (a.ld_addc % 4 == 0) && al16(a.addc);
     if (a.aux) v = v && (a.ld_aux % 4 == 0) && al16(a.aux);
     if (a.aux2) v = v && (a.ld_aux2 % 4 == 0) && al16(a.aux2);
+    if (a.y2) v = v && (a.ld_y2 % 4 == 0) && al16(a.y2);
     a.vec_out = v ? 1 : 0;
     // knob 1 = 1 forces the exact-fp32 MFMA kernels
     if (w16_ && wn_debug_get(1) != 1 && wn_gemm_rows16_ok(a)) return wn_launch_gemm_rows16(a, w16_, am0_, am1_, amo_, s);
+    if (a.epi == WN_EPI_GATE_FWD) { wn_set_error("gate-forward contraction needs the split-precision kernel (alignment / shape)"); return WN_E_UNSUPPORTED; }
     return wn_launch_gemm_rows(a, s);
   }
 };
@@ -489,6 +493,7 @@ struct BlockPtrs {
   const float* F16d; const float* F16r;   // fp16 split images of the gated conv / conv1, or null
   const float* G16u; const float* G16x;   // fp16 split images of the backward-data products, or null
   const float* G16r;                      // [W_r] alone
+  const float* F16g;                      // gated conv, row tiles [f f g g] per 64 channels (composed split-precision forward), or null
 };
 
 struct BlockBufs {
@@ -518,6 +523,22 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     h = f.P[i]; hc = k.D;
   }
   const int li = k.depth - 1;
+  // blocks too wide for the split-precision one-kernel forward: [gated conv + gate] -> [1x1 + residual] as two
+  // split-precision contractions, ahead of the exact-fp32 one-kernel forward   (knob 11 = 1 disables it)
+  if (k.F16g && k.F16r && k.Cc == 0 && !k.cb && !f.O && hc == k.R && f.ldz % 4 == 0 && wn_debug_get(1) != 1 &&
+      wn_debug_get(11) != 1) {
+    Gemm g(k.B, k.T, 2 * k.D, ceil32(2 * k.D));
+    for (int t = 0; t < k.KS; ++t) {
+      if (f.xt[t]) g.seg(f.xt[t], hc, hc, 0, nullptr);
+      else g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[li], nullptr);
+    }
+    rc = g.bias(k.bd[li]).w16(k.F16g).gate_fwd(f.AG, k.D).run(f.Z, f.ldz, s);
+    if (rc) return rc;
+    Gemm r(k.B, k.T, k.R, ceil32(k.R));
+    r.seg(f.Z, f.ldz, k.D, 0, k.Fr).bias(k.br).w16(k.F16r);
+    if (k.residual) r.addc(f.res ? f.res : f.x, k.Cin);
+    return r.run(f.x_out, k.R, s);
+  }
   if (k.fused && k.Cc == 0 && hc == k.R) {
     WnLayerFwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -835,6 +856,19 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
       add_image16(p, bi.dil.back());
       add_image16(p, bi.conv1);
     }
+  // blocks too wide for the one-kernel forward (R = D = 128): gated conv with the gate in the GEMM epilogue,
+  // then the 1x1 convolution with the residual add -- both on the split-precision streamed GEMM
+  if (!p->fused16_ok && p->LPB == 1 && p->D % 64 == 0 && m16(p->R) && m32(p->R))
+    for (BlockInfo& bi : p->blocks) {
+      const ConvInfo& c = bi.dil.back();
+      bi.f16gate = new_image16(p, 2 * p->D, p->KS * p->R);
+      for (int t = 0; t < p->KS; ++t)
+        for (int q = 0; q < p->D / 64; ++q)
+          for (int half = 0; half < 2; ++half)
+            add_piece16(p, bi.f16gate, 64, p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D + half * p->D + 64 * q,
+                        p->R, 2 * p->D, 1, t * (p->R / 16), 4 * q + 2 * half, 2 * p->D / 32);
+      add_image16(p, bi.conv1);
+    }
   // split-precision images of the generic contractions (each only when its shape qualifies:
   // K multiple of 16, N multiple of 32 and >= 64; otherwise the fp32-MFMA kernel runs)
   for (ConvInfo& c : p->finals) {
@@ -1009,6 +1043,7 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   k.Cc = 0; k.cond = nullptr; k.cb = nullptr;
   k.fused = p->fused_ok;
   if (p->fused16_ok && p->LPB == 1) { k.F16d = fragbase + bi.dil.back().frag16; k.F16r = fragbase + bi.conv1.frag16; }
+  if (bi.f16gate >= 0) { k.F16g = fragbase + bi.f16gate; k.F16r = fragbase + bi.conv1.frag16; }
   if (bi.g16u >= 0) k.G16u = fragbase + bi.g16u;
   if (bi.g16r >= 0) k.G16r = fragbase + bi.g16r;
   if (p->LPB == 1 && bi.dil[0].frag16B >= 0) k.G16x = fragbase + bi.dil[0].frag16B;
