@@ -25,6 +25,7 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //    9  = 1: no side stream in the weight-gradient phase
 //   10  > 0: time splits per utterance of the weight-gradient slabs
 //   11  =1: no composed split-precision forward for blocks too wide for the one-kernel forward (R = D = 128)
+//   12  = 1: no 256-column wide streamed kernel (N = 256 contractions as two 128-column blocks)
 //   13  = 1: 128-channel per-block weight gradients on the generic job table (no wn_wgrad_pair_kernel)
 //   14  = 1: global conditioning per block (no single contraction over all blocks)
 //   15  = 1: last block's backward without the (zero) output gradient: one-segment product on the fp32 kernel

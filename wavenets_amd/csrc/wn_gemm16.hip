@@ -404,6 +404,171 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
   }
 }
 
+// Wide form of the streamed kernel: 256 output channels per workgroup (JT = 8 row tiles per wave), so a
+// contraction with N = 256 (the folded skip sum over all blocks' gated activations, K = N_blocks * D)
+// reads its activations ONCE instead of once per 128-column block.  One k-step per chunk (8 blocks of
+// 2 KiB = 16 KiB of weight fragments, ring of 4, two chunks in flight) and a ring of FOUR activation
+// buffers per wave inside its output stage (three k-steps = 6 KiB per wave in flight: the operand stream
+// comes from HBM, the weights from L2).  Every chunk issues exactly one weight request group and one
+// activation request group -- past the end of K they are clamped re-reads into buffers nobody uses any
+// more -- so the counted wait is the same constant everywhere:
+//   issue order  w0 x0 w1 x1 x2 | w2 x3 | w3 x4 | ...   ->  "x(c), w(c) landed" = at most 2 PT + 3 PX newer.
+// Per output element the MFMA sequence is the streamed kernel's (k ascending; lo*hi, hi*lo, hi*hi).
+// Measured on the folded skip sum of configs[1] (K = 1920): 608 -> 430 us.  Knocking parts out of the loop
+// shows its phases do not overlap yet (loop + epilogue without DMA / MFMA / weight reads 123 us, + weight
+// fragment LDS reads 213, + MFMA 303, + DMA waits 430): the eight waves run in lock step behind the
+// per-chunk barrier.  Short contractions (K < 512) stay on the 128-column kernel, whose two column blocks
+// overlap each other's epilogue.
+struct WnG16W {
+  static constexpr int JT = 8, NBUF = 4, XB = 4, WAVES = 8;
+  static constexpr int CHUNK_BYTES = JT * 2048;        // one k-step of 8 row tiles
+  static constexpr int XBUF_BYTES = 2048;              // one k-step of a wave's 32 rows
+  static constexpr int PITCH = 68;
+  static constexpr int STAGE_BYTES = 32 * PITCH * 4;   // 8704 >= XB * XBUF_BYTES
+  static constexpr int LDS_BYTES = NBUF * CHUNK_BYTES + WAVES * STAGE_BYTES;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void wn_gemm_rows16_wide_kernel(WnGemmArgs a, const float* w16, int nks_total,
+                                                                     const float* absmax_in0, const float* absmax_in1,
+                                                                     float* absmax_out) {
+  using G = WnG16W;
+  constexpr int JT = G::JT, PITCH = G::PITCH;
+  static_assert(G::XB * G::XBUF_BYTES <= G::STAGE_BYTES, "activation ring must fit the output stage");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tl = lane & 31, h = lane >> 5;
+  float* stage = reinterpret_cast<float*>(smem + G::NBUF * G::CHUNK_BYTES + wave * G::STAGE_BYTES);
+  unsigned char* const xbuf = reinterpret_cast<unsigned char*>(stage);
+
+  float sc = 1.0f, inv_sc = 1.0f;
+  if (absmax_in0) {
+    float m = *absmax_in0;
+    if (absmax_in1) m = fmaxf(m, *absmax_in1);
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);
+      e = max(-100, min(100, e));
+      sc = ldexpf(1.0f, -e);
+      inv_sc = ldexpf(1.0f, e);
+    }
+  }
+
+  const int tiles_per_b = (a.T + 31) >> 5;
+  const int64_t ntiles = (int64_t)a.B * tiles_per_b;
+  const int ny = (a.JTtot + JT - 1) / JT;
+  const int gxw = gridDim.x / ny;
+  const int cb = blockIdx.x % ny, xb = blockIdx.x / ny;
+  const int64_t passes = (ntiles + (int64_t)gxw * G::WAVES - 1) / ((int64_t)gxw * G::WAVES);
+  const int jb = cb * JT;
+
+  static_assert(WN_MAXSEG == 4, "segment select below is written out for four segments");
+  const int e0 = (a.seg[0].K + 15) >> 4;
+  const int e1 = a.nseg > 1 ? e0 + ((a.seg[1].K + 15) >> 4) : nks_total;
+  const int e2 = a.nseg > 2 ? e1 + ((a.seg[2].K + 15) >> 4) : nks_total;
+  const int plane_ks0 = a.seg[0].plane_k > 0 ? a.seg[0].plane_k / 16 : 0;
+  const int64_t plane_st0 = a.seg[0].plane_stride;
+  float wmax = 0.f;
+  constexpr int PT = G::CHUNK_BYTES / 16 / 512;        // 2 weight-DMA instructions per thread and chunk
+  constexpr int PX = 2;                                // activation-DMA instructions per lane and chunk
+
+  for (int64_t pass = 0; pass < passes; ++pass) {
+    const int64_t tile = (pass * gxw + xb) * G::WAVES + wave;
+    const bool live = tile < ntiles;
+    const int b = live ? (int)(tile / tiles_per_b) : 0;
+    const int t0 = live ? (int)(tile % tiles_per_b) * 32 : 0;
+    const int t = t0 + tl;
+    const int rows_valid = live ? min(32, a.T - t0) : 0;
+    const int64_t row0 = (int64_t)b * a.T + t0;
+
+    // activations of k-step c -> activation buffer c % 4; returns whether this lane's row takes part
+    auto xdma = [&](int c) -> bool {
+      const int ks = min(c, nks_total - 1);
+      const int si = (ks >= e0) + (ks >= e1) + (ks >= e2);              // wave-uniform segment index
+      const int kk = ks - (si == 0 ? 0 : si == 1 ? e0 : si == 2 ? e1 : e2);
+      const float* bx = a.seg[si].x;
+      const int ld = a.seg[si].ldx, sh = a.seg[si].shift;
+      const int ts = t - sh;
+      const bool ok = live && t < a.T && ts >= 0 && ts < a.T;
+      const float* src = bx + ((int64_t)b * a.T + (ok ? ts : 0)) * ld + 4 * h + 16 * kk;
+      if (plane_ks0 > 0 && si == 0) src += (int64_t)(kk / plane_ks0) * plane_st0 - (int64_t)(kk / plane_ks0) * plane_ks0 * 16;
+      unsigned char* dst = xbuf + (c & (G::XB - 1)) * G::XBUF_BYTES;    // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8),
+                                       (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+      return ok && c < nks_total;
+    };
+    auto wdma = [&](int c) {
+      const int ks = min(c, nks_total - 1);
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        const int f = tid + 512 * i;
+        const int blk = f >> 7, within = f & 127;
+        const int j = min(jb + blk, a.JTtot - 1);
+        const f32x4* src = reinterpret_cast<const f32x4*>(w16) + ((int64_t)ks * a.JTtot + j) * 128 + within;
+        unsigned char* dst = smem + (c & (G::NBUF - 1)) * G::CHUNK_BYTES + (512 * i + wave * 64) * 16;   // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+
+    f32x16 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    bool okr[G::XB];
+    __syncthreads();                                   // previous pass finished with the ring and this stage
+    wdma(0);
+    okr[0] = xdma(0);
+    wdma(1);
+    okr[1] = xdma(1);
+    okr[2] = xdma(2);
+    for (int c0 = 0; c0 < nks_total; c0 += G::XB) {
+      wn_static_for<G::XB>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int c = c0 + i;
+        if (c < nks_total) {                           // workgroup-uniform
+          wdma(c + 2);
+          okr[(i + 3) & 3] = xdma(c + 3);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT + 3 * PX) : "memory");
+          asm volatile("s_barrier" ::: "memory");
+          const h8* wl = reinterpret_cast<const h8*>(smem + (i & (G::NBUF - 1)) * G::CHUNK_BYTES) + lane;
+          const f32x4* xl = reinterpret_cast<const f32x4*>(xbuf + i * G::XBUF_BYTES) + lane;
+          const f32x4 x0 = xl[0], x1 = xl[64];
+          h8 fr[2][2];
+          fr[0][0] = wl[0];
+          fr[0][1] = wl[64];
+          h8 bh, bl;
+          wn_split8g(x0, x1, okr[i] ? sc : 0.f, bh, bl);               // masked rows / k-steps contribute zero
+          wn_static_for<JT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 1 < JT) {
+              fr[(j + 1) & 1][0] = wl[((j + 1) * 2 + 0) * 64];
+              fr[(j + 1) & 1][1] = wl[((j + 1) * 2 + 1) * 64];
+            }
+            acc[j] = wn_mfma16g(fr[j & 1][1], bh, acc[j]);
+            acc[j] = wn_mfma16g(fr[j & 1][0], bl, acc[j]);
+            acc[j] = wn_mfma16g(fr[j & 1][0], bh, acc[j]);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this chunk's buffers are free again
+        }
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail requests land before the stage is reused
+    if (live) wn_g16_epilogue<JT, PITCH, 0, EPI>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+  }
+}
+
 // Thin form for the few-row contractions of queued generation (rows = utterances, <= a few hundred):
 // the streamed kernel would run them in ONE chunk-synchronised workgroup.  Here every (32-row tile,
 // 32-column tile) pair is its own single-wave workgroup that walks the whole K range with the weight
@@ -698,6 +863,12 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
   if (tiles * jt_need <= 64 && tiles <= 8 && a.epi != WN_EPI_GATE_FWD) {
     hipLaunchKernelGGL(wn_gemm_rows16_thin_kernel<8>, dim3((unsigned)tiles, (unsigned)jt_need), dim3(64), 0, s, a, w16, nks,
                        absmax_in0, absmax_in1, absmax_out);
+    WN_HIP_CHECK(hipGetLastError());
+    return WN_OK;
+  }
+  // long contractions with 256 output channels: one column block (knob 12 = 1: the 128-column streamed kernel)
+  if (jt_need == 8 && a.JTtot == 8 && a.epi == WN_EPI_PLAIN && nks >= 32 && wn_debug_get(12) != 1) {
+    hipLaunchKernelGGL((wn_gemm_rows16_wide_kernel<WN_EPI_PLAIN>), dim3((unsigned)gx), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
     WN_HIP_CHECK(hipGetLastError());
     return WN_OK;
   }
