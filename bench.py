@@ -79,7 +79,7 @@ def main():
 
   import torch
   import torch.distributed as dist
-  from wavenets_amd import WaveNet, Adam, _lib
+  from wavenets_amd import WaveNet, Adam, MeanSquaredError, _lib
   from wavenets_amd.data import synthetic_waveforms    # (oracle/ is imported by the cpu_baseline leg only)
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -103,7 +103,9 @@ def main():
 
   B, T = args.batch, args.length
   model = WaveNet(**CFG2, device=dev, seed=0)          # glorot kernels, zero biases, same on all ranks
-  model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
+  # the reference's own compile call (train.py:225-228): Adam + clipnorm and the MeanSquaredError metric, so every
+  # step also draws sample_waveform(pred) and updates the metric (src/model.py:338-346)
+  model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0), metrics=[MeanSquaredError()])
   x = synthetic_waveforms(B, T + 1, seed=1234 + rank, device=dev)
 
   def sync():
@@ -132,17 +134,19 @@ def main():
   from wavenets_amd import dp as _dp
   if rank == 0:
     _lib.check(L.wn_phase_enable(model._plan, 1))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    acc = [0.0] * 6
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    acc = [0.0] * 7
     nph = 3
     for _ in range(nph):
       ev[0].record()
-      loss_p, _, _ = model.loss_and_grads(x)
+      loss_p, samp_p, y_p = model.loss_and_grads(x, want_sample=True)   # the sample draw rides in the loss phase
       ev[1].record()
       _dp.allreduce_gradients(model.flat_grads, loss_p)      # no-op for a single replica
       ev[2].record()
       model.optimizer.apply_gradients(model)
       ev[3].record()
+      mse_p = torch.mean((y_p - samp_p) ** 2)
+      ev[4].record()
       torch.cuda.synchronize()
       ms4 = (C.c_float * 4)()
       _lib.check(L.wn_phase_read(model._plan, ms4))
@@ -150,12 +154,13 @@ def main():
         acc[i] += ms4[i]
       acc[4] += ev[1].elapsed_time(ev[2])
       acc[5] += ev[2].elapsed_time(ev[3])
+      acc[6] += ev[3].elapsed_time(ev[4])
     _lib.check(L.wn_phase_enable(model._plan, 0))
-    names = ['forward', 'loss', 'backward_data', 'weight_gradients', 'allreduce', 'optimizer']
+    names = ['forward', 'loss', 'backward_data', 'weight_gradients', 'allreduce', 'optimizer', 'metric']
     phases = {n: round(a / nph, 4) for n, a in zip(names, acc)}
   elif world > 1:                                         # the other ranks take part in the collectives
     for _ in range(3):
-      loss_p, _, _ = model.loss_and_grads(x)
+      loss_p, _, _ = model.loss_and_grads(x, want_sample=True)
       _dp.allreduce_gradients(model.flat_grads, loss_p)
       model.optimizer.apply_gradients(model)
   sync()
@@ -206,7 +211,7 @@ def main():
         'phases_ms': phases,
         'config': {'workload': 'configs[1]: 30-layer (3x10) mu-law-256 WaveNet, 64 residual / 256 skip ch, '
                                f'head [128,256], batch {B}x{T} per GPU, full train step '
-                               '(fwd+loss+bwd+allreduce+clipnorm-Adam)',
+                               '(fwd+loss+bwd+allreduce+clipnorm-Adam+sample_waveform draw+MSE metric, as train.py:225-228 compiles it)',
                    'global_batch': world * B, 'samples_per_utterance': T, 'parallelism': f'dp{world}'},
         'per_gpu_samples_per_s': value / world,
         'final_loss': logs['loss'],

@@ -180,6 +180,12 @@ int wn_inv_mulaw(const float* y, float* x, int64_t n, void* stream);
  * categorical: target int32 indices, pred probabilities; mixtures: target fp32 values. */
 int wn_loss_fn(int32_t head, const void* target, const float* pred, int64_t rows, int32_t C,
                int32_t num_mixtures, int32_t bits, float* loss_rows, void* stream);
+/* Arms the NEXT wn_train_fwd_bwd on this plan to also write sample = sample_waveform(pred) of that step
+ * (rows = B*T floats; src/model.py:338, consumed by the compiled metrics :340-346) drawn from the logits inside
+ * the step -- the same draw wn_sample_waveform(seed, offset) makes from that step's pred, without the (rows, C)
+ * probability tensor.  sample_out = NULL disarms.  WN_E_UNSUPPORTED (nothing armed): categorical head with a
+ * deterministic draw or more than 1024 classes; use pred_out + wn_sample_waveform there. */
+int wn_plan_arm_step_sample(wn_plan* plan, float* sample_out, int32_t deterministic, uint64_t seed, uint64_t offset);
 /* WaveNet.sample_waveform(pred, deterministic), src/model.py:393-503: (rows,C) -> (rows) */
 int wn_sample_waveform(int32_t head, const float* pred, int64_t rows, int32_t C,
                        int32_t num_mixtures, int32_t bits, int32_t deterministic, uint64_t seed,

@@ -711,3 +711,28 @@ def test_wide_skip_contraction_is_bit_identical_to_column_blocks():
   assert torch.equal(out, ref)
   _, inter = O.model_forward(x.double(), [p.double() for p in params], ocfg, None, return_intermediates=True)
   assert (out.cpu().double() - inter['logits']).abs().max() < ATOL_ACT
+
+
+@pytest.mark.parametrize('name', ['cat_r64', 'mol', 'gauss'])
+def test_train_step_metric_sample_drawn_inside_the_step(name):
+  """train.py:227 compiles MeanSquaredError: every step draws sample_waveform(pred) (src/model.py:338).  The
+  library draws it from the logits inside the step; the result must be the draw sample_waveform makes from
+  that step's pred (same Philox counter), so the metric is identical."""
+  from wavenets_amd import Adam, MeanSquaredError
+  kw = dict(MODEL_CASES[name])
+  x = O.synthetic_waveform(3, 301, seed=41).to(dev())
+  logs = []
+  for fused in (True, False):
+    ocfg, params, model = make_pair(seed=40, **kw)
+    model.compile(optimizer=Adam(learning_rate=1e-3, clipnorm=1.0), metrics=[MeanSquaredError()])
+    model._fused_step_sample = fused
+    for _ in range(2):
+      out = model.train_step(x)
+    logs.append(out)
+    # the sample itself, not only its mean square
+    _, samp, y = model.loss_and_grads(x, want_sample=True)
+    assert samp.shape == (3, 300, 1) and float(samp.abs().max()) <= 1.0
+    logs[-1]['_samp'] = samp.clone()
+  assert logs[0]['mean_squared_error'] == logs[1]['mean_squared_error']
+  assert logs[0]['loss'] == logs[1]['loss']
+  assert torch.equal(logs[0]['_samp'], logs[1]['_samp'])

@@ -48,7 +48,7 @@ def main():
     config['epochs'] = args.epochs
 
   import torch.distributed as dist
-  from wavenets_amd import WaveNet, Adam, callbacks, data, io, ops
+  from wavenets_amd import WaveNet, Adam, MeanSquaredError, callbacks, data, io, ops
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -89,7 +89,7 @@ def main():
                   final_layers_channels=config['final_layers_channels'], l2_reg_factor=config['l2_reg_factor'],
                   device=dev)
   opt = Adam(learning_rate=config['lr'], clipnorm=1.0)           # train.py:225-226
-  model.compile(optimizer=opt)
+  model.compile(optimizer=opt, metrics=[MeanSquaredError()])          # train.py:225-228
   print('Receptive field') if rank == 0 else None
   if rank == 0:
     print(model.receptive_field, ' samples')
@@ -115,7 +115,8 @@ def main():
   g = torch.Generator(device='cpu').manual_seed(0)
   for epoch in range(initial_epoch, config['epochs']):
     perm = torch.randperm(frames.shape[0], generator=g)          # same permutation on every rank
-    model.loss_tracker.reset_state()
+    for metric in model.metrics:                                    # Keras resets every metric per epoch
+      metric.reset_state()
     t0 = time.time()
     stop = False
     for i in range(n_batches):
@@ -128,7 +129,8 @@ def main():
     loss = model.loss_tracker.result()
     if rank == 0:
       sps = n_batches * config['batch_size'] * L / max(time.time() - t0, 1e-9)
-      print(f'Epoch {epoch + 1}/{config["epochs"]} - loss: {loss:.4f} - lr: {opt.learning_rate:g} - {sps:,.0f} samples/s')
+      extra = ''.join(f' - {k}: {v:.4f}' for k, v in logs.items() if k != 'loss')   # the compiled metrics, as Keras logs them
+      print(f'Epoch {epoch + 1}/{config["epochs"]} - loss: {loss:.4f}{extra} - lr: {opt.learning_rate:g} - {sps:,.0f} samples/s')
       if loss < best:                                               # ModelCheckpoint(save_best_only, monitor='loss')
         best = loss
         os.makedirs(run_dir, exist_ok=True)

@@ -182,12 +182,66 @@ int wn_launch_softmax(const float* logits, float* probs, int64_t rows, int C, hi
   return WN_OK;
 }
 
+// Philox4x32-10 (Salmon et al. 2011), counter = (row, offset), key = seed
+__device__ __forceinline__ void wn_philox(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key, uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float wn_u01(uint32_t r) {   // (0,1), 24-bit
+  return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// inverse-CDF categorical draw from the (unnormalised) probabilities p[0..C) of one row per wave
+// (p may live in global memory or in LDS); every lane returns the drawn class
+template <typename P>
+__device__ __forceinline__ int wn_draw_cat_row(P p, int C, int lane, int64_t row, uint64_t seed, uint64_t offset) {
+  const int per = (C + 63) / 64;               // contiguous chunk per lane
+  const int j0 = lane * per;
+  float loc = 0.f;
+  for (int j = j0; j < min(C, j0 + per); ++j) loc += fmaxf(p[j], 0.f);
+  float incl = loc;                            // inclusive scan over lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  const float total = __shfl(incl, 63);
+  uint32_t r[4];
+  wn_philox((uint64_t)row, offset, seed, r);
+  const float target = wn_u01(r[0]) * total;
+  const unsigned long long hit = __ballot(incl > target);
+  const int sel_lane = hit ? __builtin_ctzll(hit) : 63;
+  int result = C - 1;
+  if (lane == sel_lane) {
+    float run = incl - loc;
+    result = min(C, j0 + per) - 1;
+    for (int j = j0; j < min(C, j0 + per); ++j) {
+      run += fmaxf(p[j], 0.f);
+      if (run > target) { result = j; break; }
+    }
+  }
+  return __shfl(result, sel_lane);
+}
+
 // Keras sparse_categorical_crossentropy(target, softmax(logits)), from_logits=False:
 //   q = softmax(logits); p = clip(q, eps, 1-eps); loss = -(log p_t - log sum_j p_j)
 // and its gradient w.r.t. the logits (clip passes gradient where eps <= q <= 1-eps).
+// sample_out (C <= 256 only): also draw sample_waveform(softmax(logits)) of the row (src/model.py:338,407-411)
+// from the probabilities already in registers -- the values wn_softmax_kernel would write, the draw
+// wn_sample_rand_cat_kernel would make from them.
 __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, const int32_t* target,
                                                           int64_t rows, int C, float gscale,
-                                                          float* loss_rows, float* g_logits, float* absmax_out) {
+                                                          float* loss_rows, float* g_logits, float* absmax_out,
+                                                          float* sample_out, float inv_lv, uint64_t seed, uint64_t offset) {
+  __shared__ float qs[4][256];
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -212,6 +266,16 @@ __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, c
     }
     z = wn_wave_sum(z);
     const float inv = 1.0f / z;
+    if (sample_out) {
+      float* qw = qs[threadIdx.x >> 6];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (lane + 64 * k < C) qw[lane + 64 * k] = e[k] * inv;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int drawn = wn_draw_cat_row((const float*)qw, C, lane, row, seed, offset);
+      if (lane == 0) sample_out[row] = (float)drawn * inv_lv - 1.0f;
+    }
     float S = 0.f, A = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -294,10 +358,13 @@ __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, c
   }
 }
 int wn_launch_cat_loss(const float* logits, const int32_t* target, int64_t rows, int C,
-                       float gscale, float* loss_rows, float* g_logits, float* absmax_out, hipStream_t s) {
+                       float gscale, float* loss_rows, float* g_logits, float* absmax_out, hipStream_t s,
+                       float* sample_out, int bits, uint64_t seed, uint64_t offset) {
   if (rows <= 0) return WN_OK;
+  if (sample_out && C > 256) { wn_set_error("cat_loss: the in-kernel sample draw needs <= 256 classes"); return WN_E_UNSUPPORTED; }
   hipLaunchKernelGGL(wn_cat_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
-                     target, rows, C, gscale, loss_rows, g_logits, absmax_out);
+                     target, rows, C, gscale, loss_rows, g_logits, absmax_out, sample_out,
+                     sample_out ? 1.0f / (float)(1 << (bits - 1)) : 0.f, seed, offset);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
@@ -486,57 +553,72 @@ int wn_launch_sample_det(const float* pred, int64_t rows, int C, int M, int bits
   return WN_OK;
 }
 
-// Philox4x32-10 (Salmon et al. 2011), counter = (row, offset), key = seed
-__device__ __forceinline__ void wn_philox(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key, uint32_t out[4]) {
-  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ float wn_u01(uint32_t r) {   // (0,1), 24-bit
-  return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);
-}
-
 __global__ __launch_bounds__(256) void wn_sample_rand_cat_kernel(const float* pred, int64_t rows, int C,
                                                                  float inv, uint64_t seed, uint64_t offset,
                                                                  float* out) {
-  // inverse-CDF categorical draw from the (unnormalised) probabilities of one row per wave
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* p = pred + row * C;
-  const int per = (C + 63) / 64;               // contiguous chunk per lane
-  const int j0 = lane * per;
-  float loc = 0.f;
-  for (int j = j0; j < min(C, j0 + per); ++j) loc += fmaxf(p[j], 0.f);
-  float incl = loc;                            // inclusive scan over lanes
+  const int result = wn_draw_cat_row(pred + row * C, C, lane, row, seed, offset);
+  if (lane == 0) out[row] = (float)result * inv - 1.0f;
+}
+
+// The same draw straight from the logits (training step with a compiled sample metric, src/model.py:338):
+// the probabilities are those of wn_softmax_kernel (same lane assignment, same reductions), kept in LDS
+// instead of a (rows, C) tensor in HBM, so the drawn class is the one sample_waveform(softmax(logits)) draws.
+#define WN_SAMPLE_FUSED_MAXC 1024
+__global__ __launch_bounds__(256) void wn_sample_rand_cat_logits_kernel(const float* logits, int64_t rows, int C,
+                                                                        float inv_lv, uint64_t seed, uint64_t offset,
+                                                                        float* out) {
+  __shared__ float q[4][WN_SAMPLE_FUSED_MAXC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const float* l = logits + row * C;
+  if (C <= 256) {
+    // one read of the row, one exp per class (element k of a lane = class lane + 64 k: the same per-lane
+    // order of the max / sum as the loops below)
+    float v[4], e[4];
+    float m = -INFINITY;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float v = __shfl_up(incl, o);
-    if (lane >= o) incl += v;
-  }
-  const float total = __shfl(incl, 63);
-  uint32_t r[4];
-  wn_philox((uint64_t)row, offset, seed, r);
-  const float target = wn_u01(r[0]) * total;
-  const unsigned long long hit = __ballot(incl > target);
-  int sel_lane = hit ? __builtin_ctzll(hit) : 63;
-  int result = C - 1;
-  if (lane == sel_lane) {
-    float run = incl - loc;
-    result = min(C, j0 + per) - 1;
-    for (int j = j0; j < min(C, j0 + per); ++j) {
-      run += fmaxf(p[j], 0.f);
-      if (run > target) { result = j; break; }
+    for (int k = 0; k < 4; ++k) {
+      v[k] = lane + 64 * k < C ? l[lane + 64 * k] : -INFINITY;
+      m = fmaxf(m, v[k]);
     }
-    out[row] = (float)result * inv - 1.0f;
+    m = wn_wave_max(m);
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < C) { e[k] = expf(v[k] - m); z += e[k]; }
+    z = wn_wave_sum(z);
+    const float inv = 1.0f / z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < C) q[w][lane + 64 * k] = e[k] * inv;
+  } else {
+    float m = -INFINITY;
+    for (int j = lane; j < C; j += 64) m = fmaxf(m, l[j]);
+    m = wn_wave_max(m);
+    float z = 0.f;
+    for (int j = lane; j < C; j += 64) z += expf(l[j] - m);
+    z = wn_wave_sum(z);
+    const float inv = 1.0f / z;
+    for (int j = lane; j < C; j += 64) q[w][j] = expf(l[j] - m) * inv;
   }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int result = wn_draw_cat_row((const float*)q[w], C, lane, row, seed, offset);
+  if (lane == 0) out[row] = (float)result * inv_lv - 1.0f;
+}
+int wn_sample_from_logits_supported(int C) { return C <= WN_SAMPLE_FUSED_MAXC ? 1 : 0; }
+int wn_launch_sample_rand_cat_logits(const float* logits, int64_t rows, int C, int bits, uint64_t seed, uint64_t offset,
+                                     float* out, hipStream_t s) {
+  if (rows <= 0) return WN_OK;
+  if (C > WN_SAMPLE_FUSED_MAXC) { wn_set_error("sample from logits: %d classes > %d", C, WN_SAMPLE_FUSED_MAXC); return WN_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(wn_sample_rand_cat_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, rows, C,
+                     1.0f / (float)(1 << (bits - 1)), seed, offset, out);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
 }
 __global__ void wn_sample_rand_mix_kernel(const float* pred, int64_t rows, int M, int kind, uint64_t seed,
                                           uint64_t offset, float* out) {

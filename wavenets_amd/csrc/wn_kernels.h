@@ -222,9 +222,13 @@ int wn_launch_dequantize(const int32_t* idx, float* x, int64_t n, int bits, hipS
 int wn_launch_mulaw(const float* x, float* y, int64_t n, hipStream_t s);
 int wn_launch_inv_mulaw(const float* y, float* x, int64_t n, hipStream_t s);
 int wn_launch_softmax(const float* logits, float* probs, int64_t rows, int C, hipStream_t s);
+int wn_sample_from_logits_supported(int C);
+int wn_launch_sample_rand_cat_logits(const float* logits, int64_t rows, int C, int bits, uint64_t seed, uint64_t offset,
+                                     float* out, hipStream_t s);
 // categorical: Keras sparse CE on clipped probabilities; g_logits may be null (loss only)
 int wn_launch_cat_loss(const float* logits, const int32_t* target, int64_t rows, int C,
-                       float gscale, float* loss_rows, float* g_logits, float* absmax_out, hipStream_t s);
+                       float gscale, float* loss_rows, float* g_logits, float* absmax_out, hipStream_t s,
+                       float* sample_out = nullptr, int bits = 8, uint64_t seed = 0, uint64_t offset = 0);
 // from_probs variant used by WaveNet.loss_fn(target, pred) on materialised probabilities
 int wn_launch_cat_loss_probs(const float* probs, const int32_t* target, int64_t rows, int C,
                              float* loss_rows, hipStream_t s);

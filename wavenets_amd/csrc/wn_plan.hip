@@ -77,6 +77,8 @@ struct wn_plan {
   bool fused_ok = false, fused16_ok = false;
   float drop_rate = 0.f;        // Dropout rate applied to every block input in training (src/layers.py:108-111)
   uint64_t drop_seed = 0, drop_step = 0;
+  // armed by wn_plan_arm_step_sample: the next training step also draws sample_waveform(pred)
+  float* step_sample = nullptr; int step_sample_det = 0; uint64_t step_sample_seed = 0, step_sample_off = 0;
   // batched weight-gradient job table (device), valid for one (B, T) workspace layout
   WnWgJob* d_jobs = nullptr;
   WnTensorDesc* d_cov = nullptr;
@@ -1252,8 +1254,12 @@ int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float
   if (p->c.head == WN_HEAD_CATEGORICAL) {
     rc = wn_launch_quantize(ws + L.yt, reinterpret_cast<int32_t*>(ws + L.target), rows, p->c.bits, s);
     if (rc) return rc;
+    // an armed step sample (wn_plan_arm_step_sample) rides in the loss kernel when the row fits its registers
+    float* so = nullptr;
+    if (want_grad && p->step_sample && !p->step_sample_det && p->Cout <= 256) { so = p->step_sample; p->step_sample = nullptr; }
     rc = wn_launch_cat_loss(ws + L.logits, reinterpret_cast<const int32_t*>(ws + L.target), rows, p->Cout,
-                            gscale, ws + L.loss_rows, g_logits, absmax_out, s);
+                            gscale, ws + L.loss_rows, g_logits, absmax_out, s, so, p->c.bits, p->step_sample_seed,
+                            p->step_sample_off);
   } else {
     rc = wn_launch_mix_loss(ws + L.logits, ws + L.yt, rows, p->c.num_mixtures, p->c.bits,
                             p->c.head == WN_HEAD_LOGISTIC ? 1 : 2, gscale, ws + L.loss_rows, g_logits, absmax_out, s);
@@ -1474,6 +1480,24 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   if (pred_out) {
     if (p->c.head == WN_HEAD_CATEGORICAL) rc = wn_launch_softmax(ws + L.logits, pred_out, rows, p->Cout, s);
     else rc = hipMemcpyAsync(pred_out, ws + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
+    if (rc) return rc;
+  }
+  if (p->step_sample) {
+    // sample_waveform(pred) of this step (src/model.py:338) drawn from the logits while they are still hot:
+    // no (rows, C) probability tensor is written or re-read
+    float* so = p->step_sample;
+    p->step_sample = nullptr;
+    if (p->c.head == WN_HEAD_CATEGORICAL) {
+      if (p->step_sample_det) {
+        wn_set_error("step sample: deterministic categorical draws go through wn_sample_waveform");
+        return WN_E_UNSUPPORTED;
+      }
+      rc = wn_launch_sample_rand_cat_logits(ws + L.logits, rows, p->Cout, p->c.bits, p->step_sample_seed, p->step_sample_off, so, s);
+    } else {
+      // mixture heads: the model output IS the logits tensor
+      if (p->step_sample_det) rc = wn_launch_sample_det(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, so, s);
+      else rc = wn_launch_sample_rand(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, p->step_sample_seed, p->step_sample_off, so, s);
+    }
     if (rc) return rc;
   }
   if (p->phase_on) (void)hipEventRecord(p->phase_ev[2], s);
@@ -2336,6 +2360,15 @@ extern "C" int wn_loss_fn(int32_t head, const void* target, const float* pred, i
                               1.0f, loss_rows, nullptr, nullptr, s);
   wn_set_error("Loss %d not implemented.", head);
   return WN_E_UNSUPPORTED;
+}
+extern "C" int wn_plan_arm_step_sample(wn_plan* p, float* sample_out, int32_t deterministic, uint64_t seed, uint64_t offset) {
+  if (!p) { wn_set_error("arm_step_sample: null plan"); return WN_E_INVALID; }
+  if (sample_out && p->c.head == WN_HEAD_CATEGORICAL && (deterministic || !wn_sample_from_logits_supported(p->Cout))) {
+    wn_set_error("arm_step_sample: categorical head needs a stochastic draw over <= 1024 classes");
+    return WN_E_UNSUPPORTED;
+  }
+  p->step_sample = sample_out; p->step_sample_det = deterministic; p->step_sample_seed = seed; p->step_sample_off = offset;
+  return WN_OK;
 }
 extern "C" int wn_sample_waveform(int32_t head, const float* pred, int64_t rows, int32_t C, int32_t num_mixtures,
                                   int32_t bits, int32_t deterministic, uint64_t seed, uint64_t offset, float* out,

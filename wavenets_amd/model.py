@@ -124,6 +124,7 @@ class WaveNet(torch.nn.Module):
     self.loss_tracker = _Mean('loss')
     self.reg_loss = _Mean('reg_loss') if self.regularization else None
     self._sample_calls = 0
+    self._fused_step_sample = True        # train_step draws its metric sample inside the library
     # structure handles (attribute names of the reference)
     dil = s.dilations
     lpb = s.layers_per_block
@@ -338,11 +339,14 @@ class WaveNet(torch.nn.Module):
       return dist.get_world_size()
     return 1
 
-  def loss_and_grads(self, data, global_batch=None, n_replicas=None, want_pred=False):
+  def loss_and_grads(self, data, global_batch=None, n_replicas=None, want_pred=False, want_sample=False):
     """Forward + loss + backward of this replica's rows (src/model.py:319-335).
 
     Fills ``self.flat_grads`` with d(sum_local l / B_global)/d(theta); returns
-    (loss tensor[2] = {loss, reg_loss}, pred or None, y_true)."""
+    (loss tensor[2] = {loss, reg_loss}, pred or None, y_true).  ``want_sample``: the step also draws
+    ``sample_waveform(pred)`` (src/model.py:338) from the logits inside the library -- same draw, no (B,T,C)
+    probability tensor -- and returns it in place of pred; when the library cannot (deterministic / more than
+    1024 classes) pred is returned and the caller samples from it."""
     x, cond = self._split_inputs(data)
     B, T = x.shape[0], x.shape[1] - 1
     if T < 1:
@@ -355,10 +359,24 @@ class WaveNet(torch.nn.Module):
     L = _lib.lib()
     ws = self._workspace('train', L.wn_plan_workspace_floats(self._plan, B, T, 1))
     loss = torch.empty(2, dtype=torch.float32, device=self._device)
+    sample = None
+    if want_sample and self._fused_step_sample:
+      sample = torch.empty(B, T, 1, dtype=torch.float32, device=self._device)
+      if L.wn_plan_arm_step_sample(self._plan, _lib.ptr(sample), 0, 0x0402, self._sample_calls + 1) == 0:
+        self._sample_calls += 1
+      else:
+        sample = None
+    want_pred = want_pred or (want_sample and sample is None)
     pred = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device) if want_pred else None
-    _lib.check(L.wn_train_fwd_bwd(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
-                                  int(global_batch), int(n_replicas), _lib.ptr(self.flat_grads),
-                                  _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    try:
+      _lib.check(L.wn_train_fwd_bwd(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                                    int(global_batch), int(n_replicas), _lib.ptr(self.flat_grads),
+                                    _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    finally:
+      if sample is not None:
+        L.wn_plan_arm_step_sample(self._plan, None, 0, 0, 0)      # never leave a stale pointer armed
+    if want_sample:
+      return loss, (sample if sample is not None else self.sample_waveform(pred)), x[:, 1:, :]
     return loss, pred, x[:, 1:, :]
 
   def train_step(self, data):
@@ -367,12 +385,10 @@ class WaveNet(torch.nn.Module):
     if self.optimizer is None:
       raise RuntimeError('compile(optimizer=...) first')
     want_metric = len(self._metrics_from_compilation) > 0
-    loss, pred, y_true = self.loss_and_grads(data, want_pred=want_metric)
+    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric)
     from . import dp
     dp.allreduce_gradients(self.flat_grads, loss)       # no-op for a single replica
     self.optimizer.apply_gradients(self)
-    if want_metric:
-      sample = self.sample_waveform(pred)
     lv = loss.tolist()
     for metric in self.metrics:
       if metric.name == 'loss':
