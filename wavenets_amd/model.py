@@ -53,6 +53,15 @@ class MeanSquaredError:
     self.total += float(torch.mean((y_true - y_pred) ** 2))
     self.count += 1
 
+  # two-phase form used by train_step / test_step: the reduction is queued behind the step's kernels and its
+  # value comes back in the step's single device-to-host read (no second synchronisation)
+  def update_state_device(self, y_true, y_pred):
+    return torch.mean((y_true - y_pred) ** 2).reshape(1)
+
+  def commit(self, value):
+    self.total += float(value)
+    self.count += 1
+
   def result(self):
     return self.total / max(self.count, 1)
 
@@ -389,13 +398,18 @@ class WaveNet(torch.nn.Module):
     from . import dp
     dp.allreduce_gradients(self.flat_grads, loss)       # no-op for a single replica
     self.optimizer.apply_gradients(self)
-    lv = loss.tolist()
+    # metrics that can reduce on the device do so behind the optimizer; ONE read brings back loss, reg_loss and them
+    pending = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
+               if hasattr(m, 'update_state_device')]
+    lv = (torch.cat([loss] + [v for _, v in pending]) if pending else loss).tolist()
+    for (m, _), v in zip(pending, lv[2:]):
+      m.commit(v)
     for metric in self.metrics:
       if metric.name == 'loss':
         metric.update_state(lv[0])
       elif metric.name == 'reg_loss':
         metric.update_state(lv[1])
-      else:
+      elif not hasattr(metric, 'update_state_device'):
         metric.update_state(y_true, sample)
     return {m.name: m.result() for m in self.metrics}
 
