@@ -39,7 +39,13 @@ def _worker(rank, world, port, out_dir):
     loss, reg, grads, _ = O.loss_and_grads(x[rows], params, cfg, global_batch=4, n_replicas=world)
     flat = torch.cat([g.reshape(-1) for g in grads])
     lv = torch.stack([loss, reg])
-    dp.allreduce_gradients(flat, lv)
+    if step == 1:
+      dp.allreduce_gradients(flat, lv)
+    else:
+      # the form WaveNet.train_step uses: gradients and {loss, reg_loss} in ONE bucket, one collective
+      bucket = torch.cat([flat, lv])
+      dp.allreduce_bucket(bucket)
+      flat, lv = bucket[:flat.numel()], bucket[flat.numel():]
     out, off = [], 0
     for p in params:
       out.append(flat[off:off + p.numel()].view_as(p)); off += p.numel()

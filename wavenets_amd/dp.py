@@ -4,7 +4,7 @@ over xGMI on MI355X, "gloo" in the CPU tests).
 The reference trains under ``tf.distribute.MirroredStrategy`` (train.py:203): every replica
 computes gradients of ``sum_local(loss) / B_global`` (tf.nn.compute_average_loss,
 src/model.py:328-329) and the optimizer SUM-all-reduces them (src/model.py:336).  Here the
-same exchange is ONE all-reduce over the flat fp32 gradient buffer (5.0 MB for
+same exchange is ONE all-reduce over the flat fp32 gradient bucket (gradient + {loss, reg_loss}; 5.0 MB for
 BASELINE configs[2]); utterances are sharded by rows, parameters and Adam state replicated.
 Clipnorm is applied AFTER the reduction on every rank (deterministic, identical replicas;
 SURVEY.md section 8c records the Keras-version ambiguity)."""
@@ -39,3 +39,11 @@ def allreduce_gradients(flat_grads: torch.Tensor, loss: torch.Tensor, group=None
     return
   dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
   dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+
+
+def allreduce_bucket(bucket: torch.Tensor, group=None) -> None:
+  """The same exchange as ``allreduce_gradients`` when the {loss, reg_loss} pair lives right behind the flat
+  gradient in one buffer (``WaveNet._grad_bucket``): a single collective per step."""
+  if world_size() == 1:
+    return
+  dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)

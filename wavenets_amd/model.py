@@ -220,7 +220,9 @@ class WaveNet(torch.nn.Module):
         cnt = int(np.prod(shp))
         flat[o:o + cnt] = (torch.rand(cnt, generator=g) * 2 - 1) * lim
     self.flat_params = torch.nn.Parameter(flat.to(self._device), requires_grad=False)
-    self.flat_grads = torch.zeros_like(self.flat_params)
+    # gradient bucket = [flat gradient | loss, reg_loss]: the data-parallel exchange is ONE all-reduce
+    self._grad_bucket = torch.zeros(self.flat_params.numel() + 2, dtype=torch.float32, device=self._device)
+    self.flat_grads = self._grad_bucket[:self.flat_params.numel()]
     self.built = True
     if self.optimizer is not None:
       self.optimizer.build(self)
@@ -348,7 +350,8 @@ class WaveNet(torch.nn.Module):
       return dist.get_world_size()
     return 1
 
-  def loss_and_grads(self, data, global_batch=None, n_replicas=None, want_pred=False, want_sample=False):
+  def loss_and_grads(self, data, global_batch=None, n_replicas=None, want_pred=False, want_sample=False,
+                     _loss_in_bucket=False):
     """Forward + loss + backward of this replica's rows (src/model.py:319-335).
 
     Fills ``self.flat_grads`` with d(sum_local l / B_global)/d(theta); returns
@@ -367,7 +370,9 @@ class WaveNet(torch.nn.Module):
       n_replicas = world
     L = _lib.lib()
     ws = self._workspace('train', L.wn_plan_workspace_floats(self._plan, B, T, 1))
-    loss = torch.empty(2, dtype=torch.float32, device=self._device)
+    # train_step keeps {loss, reg_loss} in the gradient bucket's tail (one all-reduce); other callers get their own tensor
+    loss = self._grad_bucket[self.flat_params.numel():] if _loss_in_bucket else \
+        torch.empty(2, dtype=torch.float32, device=self._device)
     sample = None
     if want_sample and self._fused_step_sample:
       sample = torch.empty(B, T, 1, dtype=torch.float32, device=self._device)
@@ -394,9 +399,9 @@ class WaveNet(torch.nn.Module):
     if self.optimizer is None:
       raise RuntimeError('compile(optimizer=...) first')
     want_metric = len(self._metrics_from_compilation) > 0
-    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric)
+    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True)
     from . import dp
-    dp.allreduce_gradients(self.flat_grads, loss)       # no-op for a single replica
+    dp.allreduce_bucket(self._grad_bucket)              # gradients + {loss, reg_loss}; no-op for a single replica
     self.optimizer.apply_gradients(self)
     # metrics that can reduce on the device do so behind the optimizer; ONE read brings back loss, reg_loss and them
     pending = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
