@@ -436,12 +436,18 @@ class WaveNet(torch.nn.Module):
       dist.all_reduce(loss[:1], op=dist.ReduceOp.SUM)
     if want_metric:
       sample = self.sample_waveform(pred)
+    # as in train_step: device-side metric reductions first, then ONE device-to-host read
+    pending = [(m, m.update_state_device(x[:, 1:, :], sample)) for m in self._metrics_from_compilation
+               if hasattr(m, 'update_state_device')]
+    lv = (torch.cat([loss] + [v for _, v in pending]) if pending else loss).tolist()
+    for (m, _), v in zip(pending, lv[2:]):
+      m.commit(v)
     for metric in self.metrics:
       if metric.name == 'loss':
-        metric.update_state(float(loss[0]))
+        metric.update_state(lv[0])
       elif metric.name == 'reg_loss':
         continue
-      else:
+      elif not hasattr(metric, 'update_state_device'):
         metric.update_state(x[:, 1:, :], sample)
     return {m.name: m.result() for m in self.metrics if m.name != 'reg_loss'}
 
