@@ -736,3 +736,26 @@ def test_train_step_metric_sample_drawn_inside_the_step(name):
   assert logs[0]['mean_squared_error'] == logs[1]['mean_squared_error']
   assert logs[0]['loss'] == logs[1]['loss']
   assert torch.equal(logs[0]['_samp'], logs[1]['_samp'])
+
+
+@pytest.mark.parametrize('bits', [9, 11])
+def test_train_step_metric_sample_wide_categorical_heads(bits):
+  """512 classes: the draw comes from the logits in its own kernel (the row does not fit the loss kernel's
+  registers); 2048 classes: the library declines and the step falls back to pred + sample_waveform.  Either way
+  the sample is the one sample_waveform draws from the step's pred."""
+  from wavenets_amd import Adam, MeanSquaredError
+  kw = dict(blocks=3, channels=32, skip_channels=32, dilation_bound=4, final_layers_channels=[32], activation='relu', bits=bits)
+  x = O.synthetic_waveform(2, 130, seed=51).to(dev())
+  res = []
+  for fused in (True, False):
+    ocfg, params, model = make_pair(seed=50, **kw)
+    model.compile(optimizer=Adam(learning_rate=1e-3, clipnorm=1.0), metrics=[MeanSquaredError()])
+    model._fused_step_sample = fused
+    logs = model.train_step(x)
+    _, samp, _ = model.loss_and_grads(x, want_sample=True)
+    res.append((logs, samp.clone()))
+  assert res[0][0] == res[1][0]
+  assert torch.equal(res[0][1], res[1][1])
+  # sample values are left bin edges i / 2^(bits-1) - 1
+  q = (res[0][1] + 1.0) * float(1 << (bits - 1))
+  assert torch.equal(q, q.round()) and float(q.max()) < (1 << bits)
