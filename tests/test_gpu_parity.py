@@ -759,3 +759,29 @@ def test_train_step_metric_sample_wide_categorical_heads(bits):
   # sample values are left bin edges i / 2^(bits-1) - 1
   q = (res[0][1] + 1.0) * float(1 << (bits - 1))
   assert torch.equal(q, q.round()) and float(q.max()) < (1 << bits)
+
+
+def test_head_weight_gradients_on_their_own_time_split():
+  """At longer utterances the head's weight gradients are accumulated over a finer time split than the
+  blocks' (own compact slab, debug knob 0 = -1 shares the blocks').  Both arrangements against the oracle, and
+  against each other, on every gradient tensor."""
+  from wavenets_amd import _lib
+  kw = dict(MODEL_CASES['cat_r64'], blocks=10, dilation_bound=32)
+  ocfg, params, model = make_pair(seed=61, **kw)
+  x = O.synthetic_waveform(8, 3001, seed=62)      # 8 x 3000, 68 jobs: the blocks split each utterance 10-fold, the head 12-fold
+  _, _, grads_ref, _ = O.loss_and_grads(x.double(), [p.double() for p in params], ocfg)
+  got = {}
+  for knob in (0, -1):
+    try:
+      _lib.lib().wn_debug_set(0, knob)
+      model.loss_and_grads(x.to(dev()))
+      got[knob] = [g.clone() for g in model.gradients()]
+    finally:
+      _lib.lib().wn_debug_set(0, 0)
+  differ = 0
+  for n, a, b, r in zip(model.variable_names, got[0], got[-1], grads_ref):
+    scale = max(r.abs().max().item(), 1e-6)
+    assert (a.cpu().double() - r).abs().max().item() < 1e-4 * scale + 1e-7, n
+    assert (b.cpu().double() - r).abs().max().item() < 1e-4 * scale + 1e-7, n
+    differ += int(not torch.equal(a, b))
+  assert differ > 0          # a different summation order really ran (head tensors only)

@@ -13,6 +13,7 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 // debug / tuning knobs (not part of the reference surface): small integer registers read by the
 // launchers, settable from tools/ scripts without rebuilding
 //    0  fused fp32 block-forward kernel variant / ablations
+//    0  = -1: the head's weight gradients share the blocks' slab and time-split count; > 0: that many time splits per utterance
 //    1  = 1: exact-fp32 MFMA kernels everywhere (no fp16 hi/lo split)
 //    2  = 1: no resident-weights rows GEMM (streamed form instead)
 //    3  = 1: weight gradients alone stay exact fp32

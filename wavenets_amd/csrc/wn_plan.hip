@@ -94,6 +94,7 @@ struct wn_plan {
   // side stream: the low-occupancy generic weight-gradient jobs overlap the per-block / skip kernels
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int head_first = 0, cov_head_first = 0;   // job / coverage tables: the head's entries come last
   WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
   int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
@@ -241,6 +242,9 @@ struct WsLayout {
   int64_t slab, slab_floats;
   std::vector<int64_t> GU, GH, GO, GF;  // deferred-wgrad mode: per-block g_u, g_h (N+1), g_o; per-final g
   int64_t bslab; int bsplits;           // batched slab [B*bsplits][nparams]
+  // the head's weight gradients get their own, finer time split: a compact slab [B*hsplits][head_span] over the
+  // contiguous parameter range of the final layers (head_base = its first float); 0 splits = share bslab
+  int64_t hslab; int hsplits; int64_t head_base, head_span;
   int64_t GZS;                          // [rows][N*D] precomputed W_s g_skip of every block, or 0
   std::vector<int64_t> XD;              // dropout: dropped copy of every block input (training)
   int64_t gxd;                          // dropout: scratch for d loss / d (dropped input)
@@ -354,6 +358,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     L.slab_floats = need;
     L.slab = cv.take(need);
     L.bslab = 0; L.bsplits = 0;
+    L.hslab = 0; L.hsplits = 0; L.head_base = 0; L.head_span = 0;
     if (deferred_wgrad(p)) {
       for (int b = 0; b < p->N; ++b) L.GU.push_back(cv.take(rows * 2 * p->D));
       for (int b = 0; b <= p->N; ++b) L.GH.push_back(cv.take(rows * p->R));
@@ -367,9 +372,29 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
       if (wn_debug_get(10) > 0) sp = std::max(1, std::min(wn_debug_get(10), maxsp));   // knob 10: time splits per utterance
       L.bsplits = sp;
       L.bslab = cv.take((int64_t)B * sp * p->nparams);
+      // The head's few products (4-8 jobs each) cannot fill the chip at the blocks' split count (one wave per
+      // SIMD with one chunk of look-ahead is latency bound): ~1.5 waves per SIMD for them.  Measured at
+      // configs[1] (same-process sweep, ms per step): shared 7.64 | 8 splits 7.68 | 12: 7.57 | 16: 7.71 |
+      // 24: 7.63 | 32: 7.67 | 48: 7.71 -- a shallow, irregular optimum.
+      // knob 0 = -1: share the blocks' slab and split count; > 0: that many splits
+      if (!p->finals.empty() && wn_debug_get(0) >= 0) {
+        int njh = 0;
+        for (const ConvInfo& c : p->finals) njh += jobs_for(c.cin, c.cout);
+        int hs = (int)((1536 + (int64_t)njh * B - 1) / ((int64_t)njh * B));
+        if (wn_debug_get(0) > 0) hs = wn_debug_get(0);
+        hs = std::max(sp, std::min(hs, maxsp));
+        if (hs > sp) {
+          L.head_base = p->tensors[p->finals.front().kernel_t].off;
+          const TensorInfo& last = p->tensors[p->finals.back().bias_t];
+          L.head_span = last.off + last.len - L.head_base;
+          L.hsplits = hs;
+          L.hslab = cv.take((int64_t)B * hs * L.head_span);
+        }
+      }
     }
   } else {
     L.bslab = 0; L.bsplits = 0;
+    L.hslab = 0; L.hsplits = 0; L.head_base = 0; L.head_span = 0;
     L.g_a = L.g_b = L.g_skipsum = L.g_h0 = L.g_h1 = L.g_o = L.g_p = L.slab = 0;
     L.slab_floats = 0;
   }
@@ -1366,6 +1391,8 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       cover(bi.conv_skip.kernel_t); cover(bi.conv_skip.bias_t);
     }
   }
+  p->head_first = (int)jobs.size();
+  p->cov_head_first = (int)cov.size();
   for (size_t i = 0; i < p->finals.size(); ++i) {
     const ConvInfo& c = p->finals[i];
     const int64_t xin = (i == 0) ? (p->c.use_skip ? L.skipsum : L.H[p->N]) : L.HA[i - 1];
@@ -1617,8 +1644,17 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       WN_HIP_CHECK(hipEventRecord(p->ev_fork, s));
       WN_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
     }
-    rc = wn_launch_wgrad_batched(p->d_jobs, p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, fork ? p->side : s);
+    const bool head_own = L.hsplits > 0 && p->head_first < p->njobs;
+    rc = wn_launch_wgrad_batched(p->d_jobs, head_own ? p->head_first : p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits,
+                                 fork ? p->side : s);
     if (rc) return rc;
+    if (head_own) {
+      // job and coverage offsets are offsets into the flat parameter buffer: the compact slab is addressed
+      // through a base shifted by -head_base with the head span as its row pitch
+      rc = wn_launch_wgrad_batched(p->d_jobs + p->head_first, p->njobs - p->head_first, ws, ws + L.hslab - L.head_base,
+                                   L.head_span, B, T, L.hsplits, fork ? p->side : s);
+      if (rc) return rc;
+    }
     if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
     for (int kd = 1; kd <= 2; ++kd)
       if (p->jobs_pairk && p->pair_count[kd] > 0) {
@@ -1655,8 +1691,13 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
                                 p->tensors[b0.conv_cond.bias_t].off, bst, s);
       if (rc) return rc;
     }
-    rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov, p->ncov, s);
+    rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov, head_own ? p->cov_head_first : p->ncov, s);
     if (rc) return rc;
+    if (head_own) {
+      rc = wn_launch_reduce_table(ws + L.hslab - L.head_base, B * L.hsplits, L.head_span, grads, p->d_cov + p->cov_head_first,
+                                  p->ncov - p->cov_head_first, s);
+      if (rc) return rc;
+    }
     if (!p->c.use_skip && p->S > 0) {
       for (const BlockInfo& bi : p->blocks) {     // unused skip convs: zero gradients
         rc = wn_launch_fill(grads + p->tensors[bi.conv_skip.kernel_t].off, 0.f, p->tensors[bi.conv_skip.kernel_t].len, s);
