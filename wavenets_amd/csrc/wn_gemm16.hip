@@ -866,8 +866,9 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
     WN_HIP_CHECK(hipGetLastError());
     return WN_OK;
   }
-  // long contractions with 256 output channels: one column block (knob 12 = 1: the 128-column streamed kernel)
-  if (jt_need == 8 && a.JTtot == 8 && a.epi == WN_EPI_PLAIN && nks >= 32 && wn_debug_get(12) != 1) {
+  // long contractions with 256 output channels over enough rows to fill the chip with one column block (fewer rows,
+  // e.g. the sliding-window sampler's: two column blocks give twice the workgroups); knob 12 = 1: never
+  if (jt_need == 8 && a.JTtot == 8 && a.epi == WN_EPI_PLAIN && nks >= 32 && tiles >= 2048 && wn_debug_get(12) != 1) {
     hipLaunchKernelGGL((wn_gemm_rows16_wide_kernel<WN_EPI_PLAIN>), dim3((unsigned)gx), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
     WN_HIP_CHECK(hipGetLastError());
     return WN_OK;
