@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: WaveNet training-step throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--global-batch G]
 
-A "step" is one full data-parallel training step (src/model.py:309-348): shift-by-one, forward,
-loss, backward, SUM all-reduce of the flat gradient over RCCL, per-tensor clipnorm + Keras Adam
-(train.py:225-226) on one batch of synthetic 16 kHz mu-law waveforms already resident in HBM.
-Workload = BASELINE.json configs[1] (30-layer 3x10 mu-law-256 WaveNet, 64 residual / 256 skip
-channels, batch 8 x 16000 per GPU); N GPUs run configs[2]'s data-parallel form (weak scaling:
-per-GPU batch fixed at 8, global batch 8 N).  The metric-only sample_waveform call of the
-reference (src/model.py:338) is excluded.
+A "step" is one full data-parallel training step as train.py:225-228 compiles it (src/model.py:309-348):
+shift-by-one, forward, loss, backward, SUM all-reduce of the flat gradient over RCCL, per-tensor clipnorm +
+Keras Adam, and -- because the reference compiles a MeanSquaredError metric -- the per-step
+sample_waveform(pred) draw and the metric update, on one batch of synthetic 16 kHz mu-law waveforms already
+resident in HBM.  Workload = BASELINE.json configs[1] (30-layer 3x10 mu-law-256 WaveNet, 64 residual / 256
+skip channels, batch 8 x 16000 per GPU); N GPUs run configs[2]'s data-parallel form (weak scaling: per-GPU
+batch 8, global batch 8 N -- global batch 64 at N = 8, as configs[2] names it).
+
+  --gpus N > 1 without an enclosing torch.distributed.run: this script starts the N ranks itself (child
+  processes of `python -m torch.distributed.run`, before anything here touches the GPU) and relays rank 0's line.
+  --global-batch G: STRONG scaling -- the global batch is fixed at G, every rank takes G / N utterances
+  (north_star: global batch 64); without it the line is weak scaling and a short strong-scaling measurement at
+  global batch 64 is reported beside it ("strong_scaling").
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     -- the fused residual-block forward kernel (the "dilated-conv forward" of
-                  north_star): algorithmic bytes 4 B T (2R + S) per launch / live HIP-event
-                  time per launch, against the 8 TB/s HBM3E peak
-  cpu_baseline -- the CPU oracle (restated reference, PyTorch CPU) timed on this host's cores
-                  on a bounded sample (configs[0]: 10-layer, 32 ch, 1 x 16000)
+  roofline     -- SURVEY.md 8(d): the residual-block STACK forward.  achieved = N_blocks * 4 B T (2R + S) /
+                  t_stack_fwd, t_stack_fwd = HIP events on the launch stream from the first block launch to the
+                  end of the folded skip contraction (the skip tensors of the reference's signature are produced
+                  there), against the 8 TB/s HBM3E peak.  "fused_block_kernel" beside it: the dominant kernel on
+                  its own counter bytes.
+  cpu_baseline -- the CPU oracle (restated reference, PyTorch CPU) timed on this host's cores on a bounded
+                  sample of the same workload
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,7 +41,46 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 CFG2 = dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024,
             final_layers_channels=[128, 256], activation='leaky_relu', bits=8)
-CFG1 = dict(blocks=10, channels=32, dilation_bound=1024, final_layers_channels=[], bits=8)
+STRONG_GLOBAL_BATCH = 64   # north_star / configs[2]
+
+
+def parse_args(argv=None):
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--warmup', type=int, default=10)
+  ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (utterances), weak scaling')
+  ap.add_argument('--global-batch', type=int, default=0,
+                  help='strong scaling: fixed global batch, split over the ranks (0 = weak scaling)')
+  ap.add_argument('--length', type=int, default=16000, help='predicted samples per utterance')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-strong-leg', action='store_true', help='skip the extra global-batch-64 measurement')
+  ap.add_argument('--cpu-budget', type=float, default=20.0)
+  return ap.parse_args(argv)
+
+
+def self_launch(args):
+  """--gpus N outside torch.distributed.run: start the ranks as children and relay rank 0's JSON line.
+  Runs before torch is imported, so this process never touches the GPU."""
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  line = None
+  for ln in res.stdout.splitlines():
+    if ln.startswith('{') and '"metric"' in ln:
+      line = ln
+  if res.returncode != 0 or line is None:
+    sys.stderr.write(res.stdout[-4000:])
+    raise SystemExit(res.returncode or 1)
+  print(line)
+  raise SystemExit(0)
 
 
 def cpu_baseline(budget_s: float = 20.0):
@@ -66,27 +113,33 @@ def cpu_baseline(budget_s: float = 20.0):
                     f'8 utterances (batch 1x16000) with the PyTorch-CPU oracle, {dt * 1e3:.0f} ms/step'}
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=10)
-  ap.add_argument('--warmup', type=int, default=3)
-  ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (utterances)')
-  ap.add_argument('--length', type=int, default=16000, help='predicted samples per utterance')
-  ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-budget', type=float, default=20.0)
-  args = ap.parse_args()
+def _profile_rows(pattern):
+  """Newest committed rocprofv3 summary matching profiles/<pattern> as a list of csv rows."""
+  import csv
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+  if not files:
+    return []
+  with open(files[-1]) as f:
+    return list(csv.DictReader(f))
 
+
+def main():
+  args = parse_args()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.gpus > 1 and world == 1 and 'RANK' not in os.environ:
+    self_launch(args)                                     # does not return
+
+  import ctypes as C
   import torch
   import torch.distributed as dist
   from wavenets_amd import WaveNet, Adam, MeanSquaredError, _lib
   from wavenets_amd.data import synthetic_waveforms    # (oracle/ is imported by the cpu_baseline leg only)
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if args.gpus > 1 and world != args.gpus:
-    raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
   # WN_BENCH_BACKEND=gloo lets several ranks share ONE GPU (rehearsal of the multi-rank path on a
   # single-GPU box); the measured configuration is always nccl (= RCCL), one rank per GPU
   backend = os.environ.get('WN_BENCH_BACKEND', 'nccl')
@@ -101,32 +154,62 @@ def main():
     else:
       dist.init_process_group(backend)
 
-  B, T = args.batch, args.length
-  model = WaveNet(**CFG2, device=dev, seed=0)          # glorot kernels, zero biases, same on all ranks
-  # the reference's own compile call (train.py:225-228): Adam + clipnorm and the MeanSquaredError metric, so every
-  # step also draws sample_waveform(pred) and updates the metric (src/model.py:338-346)
-  model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0), metrics=[MeanSquaredError()])
-  x = synthetic_waveforms(B, T + 1, seed=1234 + rank, device=dev)
+  T = args.length
+  strong = args.global_batch > 0
+  if strong:
+    if args.global_batch % world:
+      raise SystemExit(f'--global-batch {args.global_batch} is not divisible by {world} ranks')
+    B = args.global_batch // world
+  else:
+    B = args.batch
+  L = _lib.lib()
+  nblk = CFG2['blocks']
 
   def sync():
     if world > 1:
       dist.barrier()
     torch.cuda.synchronize()
 
+  def make_model():
+    model = WaveNet(**CFG2, device=dev, seed=0)          # glorot kernels, zero biases, same on all ranks
+    # the reference's own compile call (train.py:225-228): Adam + clipnorm and the MeanSquaredError metric, so
+    # every step also draws sample_waveform(pred) and updates the metric (src/model.py:338-346)
+    model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0), metrics=[MeanSquaredError()])
+    return model
+
+  def timed_steps(model, x, steps, warmup):
+    """(total seconds for `steps` steps bracketed as the contract says, per-step host times, last logs)."""
+    for _ in range(warmup):
+      logs = model.train_step(x)
+    sync()
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      ts = time.perf_counter()
+      logs = model.train_step(x)                         # ends with the step's one device-to-host read
+      per.append(time.perf_counter() - ts)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), per, logs
+
+  model = make_model()
+  x = synthetic_waveforms(B, T + 1, seed=1234 + rank, device=dev)
   for _ in range(args.warmup):
     model.train_step(x)
-  L = _lib.lib()
-  nblk = CFG2['blocks']
   _lib.check(L.wn_prof_enable(model._plan, nblk * min(args.steps, 20)))
-  sync()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    logs = model.train_step(x)
-  sync()
-  dt = time.perf_counter() - t0
+  _lib.check(L.wn_stack_prof_enable(model._plan, min(args.steps, 50)))
+  dt, per_step, logs = timed_steps(model, x, args.steps, 0)
   n_l, avg_ms = C.c_int32(), C.c_float()
   _lib.check(L.wn_prof_read(model._plan, C.byref(n_l), C.byref(avg_ms)))
   _lib.check(L.wn_prof_enable(model._plan, 0))
+  n_s, stack_ms = C.c_int32(), C.c_float()
+  _lib.check(L.wn_stack_prof_read(model._plan, C.byref(n_s), C.byref(stack_ms)))
+  _lib.check(L.wn_stack_prof_enable(model._plan, 0))
+  ms_per_step = dt / args.steps * 1e3
+  value = world * B * T * args.steps / dt
 
   # where the step goes (untimed extra steps): phase marks inside wn_train_fwd_bwd (HIP events on the launch
   # stream) + torch events around the gradient all-reduce and the optimizer
@@ -167,44 +250,54 @@ def main():
 
   # the same step with the exact-fp32 MFMA kernels (debug knob 1), reported beside the default
   L.wn_debug_set(1, 1)
-  model.train_step(x)
-  sync()
-  t1 = time.perf_counter()
-  nf = max(2, args.steps // 3)
-  for _ in range(nf):
-    model.train_step(x)
-  sync()
-  dt_fp32 = (time.perf_counter() - t1) / nf
+  nf = max(2, min(args.steps // 3, 10))
+  dt_fp32, _, _ = timed_steps(model, x, nf, 1)
+  dt_fp32 /= nf
   L.wn_debug_set(1, 0)
 
-  t = torch.tensor([dt], dtype=torch.float64, device=dev)
-  if world > 1:
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-  dt = float(t.item())
-  ms_per_step = dt / args.steps * 1e3
-  value = world * B * T * args.steps / dt
+  # strong-scaling leg (north_star: global batch 64 split over the ranks): a short run beside the weak line
+  strong_leg = None
+  if not strong and not args.no_strong_leg and STRONG_GLOBAL_BATCH % world == 0:
+    Bs = STRONG_GLOBAL_BATCH // world
+    if Bs == B:
+      strong_leg = {'global_batch': STRONG_GLOBAL_BATCH, 'per_gpu_batch': Bs, 'ms_per_step': ms_per_step, 'value': value,
+                    'steps': args.steps, 'note': 'same run as the headline (per-GPU batch coincides)'}
+    else:
+      del model
+      torch.cuda.empty_cache()
+      model = make_model()
+      xs = synthetic_waveforms(Bs, T + 1, seed=4321 + rank, device=dev)
+      ns = max(3, min(args.steps, 10))
+      dts, _, _ = timed_steps(model, xs, ns, 2)
+      strong_leg = {'global_batch': STRONG_GLOBAL_BATCH, 'per_gpu_batch': Bs, 'ms_per_step': dts / ns * 1e3,
+                    'value': STRONG_GLOBAL_BATCH * T * ns / dts, 'steps': ns}
 
   if rank == 0:
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE
-    # x2 gfx950 correction + WRITE_SIZE, profiles/r01_train_pmc_hbm_traffic.csv); bench.py cannot run
-    # the counter passes itself
-    traffic = None
-    try:
-      import csv
-      with open(os.path.join(ROOT, 'profiles', 'r01_train_pmc_hbm_traffic.csv')) as f:
-        for row in csv.DictReader(f):
-          if 'wn_layer_fwd_f16_kernel' in row['kernel'] and (B, T) == (8, 16000):
-            traffic = float(row['total_bytes_corrected'])
-    except OSError:
-      pass
+    per_ms = sorted(p * 1e3 for p in per_step)
+
+    def pct(q):
+      return per_ms[min(len(per_ms) - 1, int(round(q * (len(per_ms) - 1))))]
+
+    # HBM bytes per launch of the dominant kernel and MFMA busy share from the committed rocprofv3 PMC passes
+    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the counter passes itself
+    traffic, mfma_busy = None, None
+    for row in _profile_rows('r0*_train_pmc_hbm_traffic.csv'):
+      if 'wn_layer_fwd_f16_kernel' in row['kernel'] and (B, T) == (8, 16000):
+        traffic = float(row['total_bytes_corrected'])
+    for row in _profile_rows('r0*_train_pmc_sq.csv'):
+      if 'wn_layer_fwd_f16_kernel' in row['kernel']:
+        mfma_busy = float(row['mfma_busy_per_wave_cycle'])
     R, S = CFG2['channels'], CFG2['skip_channels']
     bytes_layer = 4.0 * B * T * (2 * R + S)          # read x, write x_out, write skip
-    achieved = bytes_layer / (avg_ms.value * 1e-3) / 1e9 if avg_ms.value > 0 else 0.0
+    stack_bytes = nblk * bytes_layer
+    achieved = stack_bytes / (stack_ms.value * 1e-3) / 1e9 if stack_ms.value > 0 else 0.0
+    kern_gbs = (traffic / (avg_ms.value * 1e-3) / 1e9) if (traffic and avg_ms.value > 0) else None
     out = {
         'metric': 'audio samples/sec (training step, 16 kHz mu-law)',
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'ms_per_step_median': pct(0.5), 'ms_per_step_p10': pct(0.1), 'ms_per_step_p90': pct(0.9),
         'math': 'fp32 tensors; contractions as fp16 hi/lo split, 3 products on v_mfma_f32_32x32x16_f16 with fp32 '
                 'accumulate (|err| <= 6e-7 on O(1) results, parity-tested at 1e-4); exact-fp32 MFMA selectable',
         'exact_fp32_mfma': {'ms_per_step': dt_fp32 * 1e3, 'value': world * B * T / dt_fp32},
@@ -214,12 +307,23 @@ def main():
                                '(fwd+loss+bwd+allreduce+clipnorm-Adam+sample_waveform draw+MSE metric, as train.py:225-228 compiles it)',
                    'global_batch': world * B, 'samples_per_utterance': T, 'parallelism': f'dp{world}'},
         'per_gpu_samples_per_s': value / world,
+        'strong_scaling': strong_leg,
         'final_loss': logs['loss'],
-        'roofline': {'bound': 'hbm', 'kernel': 'wn_layer_fwd_f16_kernel (fused residual-block forward, training mode)',
+        'roofline': {'bound': 'hbm',
+                     'kernel': 'residual-block stack forward: 30 x wn_layer_fwd_f16_kernel + the folded skip contraction '
+                               '(wn_gemm_rows16_wide_kernel), SURVEY.md 8(d)',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'algorithmic_bytes_per_launch': bytes_layer, 'avg_launch_ms': avg_ms.value,
-                     'launches_timed': n_l.value},
+                     'algorithmic_bytes_per_stack_pass': stack_bytes, 'algorithmic_bytes_per_block': bytes_layer,
+                     't_stack_fwd_ms': stack_ms.value, 'passes_timed': n_s.value,
+                     'fused_block_kernel': {'kernel': 'wn_layer_fwd_f16_kernel', 'avg_launch_ms': avg_ms.value,
+                                            'launches_timed': n_l.value, 'counter_bytes_per_launch': traffic,
+                                            'counter_GBps': kern_gbs,
+                                            'counter_frac_of_peak': (kern_gbs / HBM_PEAK_GBS) if kern_gbs else None,
+                                            'mfma_busy_per_wave_cycle': mfma_busy},
+                     'note': 'traffic = HBM bytes per launch of the fused block kernel (profiles/, FETCH x2 + WRITE); it '
+                             'writes x_out, z and the saved sigmoid -- the skip tensors of the algorithmic signature are '
+                             'produced by the folded contraction inside the timed stack'},
     }
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args.cpu_budget)

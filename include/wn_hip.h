@@ -91,7 +91,9 @@ int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t T, int32_t
 
 /* ---- Dropout(rate) on every block input in training calls (src/layers.py:108-111,195-196; WaveNet
  * keyword `dropout`).  The keep-mask is a counter-based hash of (seed, block, step, element); `step`
- * is the value BEFORE the next wn_train_fwd_bwd (each call pre-increments it).  rate 0 disables. */
+ * is used as given by every following training call: the CALLER owns the counter (the Python mirror sets
+ * step = call_index * world_size + rank + 1 before each step, so that replicas draw independent masks as
+ * under MirroredStrategy, and stores call_index in its checkpoints).  rate 0 disables. */
 int wn_plan_set_dropout(wn_plan* p, float rate, uint64_t seed, uint64_t step);
 uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* test hook */
 
@@ -103,6 +105,10 @@ uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* t
 int wn_debug_set(int key, int value);     /* tuning knobs for tools/ scripts */
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
 int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
+/* the whole residual-block stack of a forward pass: one event pair per pass from the first block launch to
+ * the end of the folded skip contraction = t_stack_fwd of SURVEY.md 8(d); read returns passes and the average */
+int wn_stack_prof_enable(wn_plan* p, int32_t max_passes);
+int wn_stack_prof_read(wn_plan* p, int32_t* passes, float* avg_ms);
 /* phase marks of wn_train_fwd_bwd: ms4 = {forward, loss, backward-data chain, weight gradients + rest}
  * of the last call (read after a stream sync) */
 int wn_phase_enable(wn_plan* p, int32_t on);

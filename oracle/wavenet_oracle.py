@@ -285,6 +285,34 @@ def layer_forward(x: torch.Tensor, layer_params: Sequence[torch.Tensor], *,
   return x_out, skip
 
 
+def layer_generate(gathered: torch.Tensor, layer_params: Sequence[torch.Tensor], *,
+                   has_skip: bool, cond: Optional[torch.Tensor] = None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+  """WaveNetLayer.generate, src/layers.py:226-290: the single-step form of a depth-1 block for a
+  queued sampler.  ``gathered`` (B, k, R) already holds the taps the dilated conv would read,
+  oldest first ([x[t-d], x[t]] for k = 2); the conv runs undilated with VALID padding (:257-260),
+  then conv_cond (:263-267), the gate (:271-273), conv1 (:276-278), conv_skip or the pre-residual
+  alias (:281-286) and the residual with the LAST tap (:251, :289).  Returns (B,1,R), (B,1,S)."""
+  cur = _ParamCursor(list(layer_params))
+  kern, b = cur.take(2)                            # (k, R, 2D)
+  kr, br = cur.take(2)
+  if has_skip:
+    ks, bs = cur.take(2)
+  k = kern.shape[0]
+  if gathered.shape[1] != k:
+    raise ValueError('gathered input must hold exactly kernel-size taps')
+  residual = gathered[:, -1:, :]                   # src/layers.py:251
+  h = sum(gathered[:, j:j + 1, :] @ kern[j] for j in range(k)) + b
+  if cond is not None:
+    kc, bc = cur.take(2)
+    h = h + conv1x1(cond, kc, bc)
+  D = h.shape[-1] // 2
+  z = torch.tanh(h[..., :D]) * torch.sigmoid(h[..., D:])
+  x_out = conv1x1(z, kr, br)
+  skip = conv1x1(z, ks, bs) if has_skip else x_out
+  return x_out + residual, skip
+
+
 def _params_per_block(cfg: OracleConfig) -> int:
   n = 2 * cfg.layers_per_block + 2
   if cfg.skip_channels is not None:
@@ -474,6 +502,24 @@ def sample_waveform_deterministic(pred: torch.Tensor, cfg: OracleConfig) -> torc
 # --------------------------------------------------------------------------------------
 # training step  (src/model.py:309-348, train.py:225-226)
 # --------------------------------------------------------------------------------------
+def mixture_sample_cdf(pred_row: torch.Tensor, cfg: OracleConfig, v: torch.Tensor) -> torch.Tensor:
+  """P(sample <= v), -1 <= v < 1, of the NON-deterministic mixture samplers for one prediction row
+  (3M,): component m is drawn with probability softmax(w)_m, then x = mu_m + e^{s_m} eps with
+  eps = ln z - ln(1-z), z ~ U(0,1) (standard logistic; src/model.py:463-483) or eps ~ N(0,1)
+  (src/model.py:423-443), and x is clipped to [-1, 1] (atoms at both ends; no floor on s here, unlike
+  the losses).  TF's random stream cannot be matched, so the product's draws are tested against this law."""
+  M = cfg.num_mixtures
+  p = pred_row.double()
+  w = torch.softmax(p[:M], -1)
+  mu, sc = p[M:2 * M], torch.exp(p[2 * M:])
+  a = (v.double().unsqueeze(-1) - mu) / sc
+  if cfg.sampling_function == 'logistic':
+    F = torch.sigmoid(a)
+  else:
+    F = 0.5 * (1.0 + torch.erf(a / math.sqrt(2.0)))
+  return (F * w).sum(-1)
+
+
 def l2_penalty(params: Sequence[torch.Tensor], cfg: OracleConfig) -> torch.Tensor:
   """sum over every kernel of l2 * sum(W^2)  (kernel_regularizer=L2(l2) on every conv and
   dense, src/layers.py:74,88,96,104,120; src/model.py:88,110,118,146)."""

@@ -1,0 +1,126 @@
+"""The exact BASELINE.json networks at their full depth against the fp64 oracle.
+
+configs[1] (30-layer mu-law-256, 64 residual / 256 skip channels), configs[3] (30-layer
+mixture-of-logistics head with 10 mixtures, 128 residual channels, 16 bits) and configs[4] (configs[1] with
+global conditioning: 110-way one-hot speaker id through the mapping net [8, 16, 32]) are built with their 30
+blocks / dilations 1..512 (x3) and run on B = 2 utterances of T = 3500 samples (longer than the receptive
+field, 3071): logits, loss and EVERY gradient tensor are compared with the oracle in both contraction modes
+at north_star's bar -- 1e-4 absolute per activation, gradients 1e-4 relative to each tensor's scale.
+SURVEY.md section 7 hard part 2 ("1e-4 through 30 residual layers + softmax") is what this file checks.
+Reference maths: src/model.py:79-122,213-239, src/layers.py:178-224 (conditioning add: :203-204).
+"""
+import pytest
+import torch
+
+from oracle import wavenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ATOL_ACT = 1e-4
+
+NETS = {
+    'configs1_cat_r64': dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024,
+                             final_layers_channels=[128, 256], activation='leaky_relu', bits=8),
+    'configs3_mol10_r128': dict(blocks=30, channels=128, skip_channels=256, dilation_bound=1024,
+                                final_layers_channels=[128, 256], activation='leaky_relu', num_mixtures=10,
+                                sampling_function='logistic', bits=16),
+    'configs4_globalcond_r64': dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024,
+                                    final_layers_channels=[128, 256], activation='leaky_relu', bits=8,
+                                    conditioning='global', mapping_layers=[8, 16, 32],
+                                    mapping_activation='leaky_relu', cond_inputs=110),
+}
+B, T = 2, 3500
+
+
+def dev():
+  return torch.device('cuda', 0)
+
+
+_ORACLE = {}
+
+
+def _oracle(name):
+  """fp64 oracle results of one network, computed once for both math modes."""
+  if name in _ORACLE:
+    return _ORACLE[name]
+  kw = dict(NETS[name])
+  cond_inputs = kw.pop('cond_inputs', 0)
+  ocfg = O.OracleConfig(**kw, cond_inputs=cond_inputs)
+  params = O.init_params(ocfg, seed=21, bias_range=0.1)
+  x = O.synthetic_waveform(B, T + 1, seed=31)
+  cond = None
+  if cond_inputs:
+    ids = torch.randint(0, cond_inputs, (B,), generator=torch.Generator().manual_seed(5))
+    cond = torch.nn.functional.one_hot(ids, cond_inputs).float()         # speaker id -> one-hot
+  pd = [p.double() for p in params]
+  cd = cond.double() if cond is not None else None
+  torch.set_num_threads(16)
+  _, inter = O.model_forward(x[:, :-1].double(), pd, ocfg, cd, return_intermediates=True)
+  loss, _, grads, _ = O.loss_and_grads(x.double(), pd, ocfg, cd)
+  _ORACLE[name] = (ocfg, params, x, cond, inter['logits'], loss, grads)
+  return _ORACLE[name]
+
+
+@pytest.fixture(params=['split', 'fp32'])
+def math_mode(request):
+  from wavenets_amd import _lib
+  _lib.lib().wn_debug_set(1, 1 if request.param == 'fp32' else 0)
+  yield request.param
+  _lib.lib().wn_debug_set(1, 0)
+
+
+def _model(name, params):
+  from wavenets_amd import WaveNet
+  kw = dict(NETS[name])
+  cond_inputs = kw.pop('cond_inputs', 0)
+  model = WaveNet(**kw, device=dev())
+  if cond_inputs:
+    model.build([(1, 8, 1), (1, cond_inputs)])
+  model.set_weights([p.numpy() for p in params])
+  return model
+
+
+@pytest.mark.parametrize('name', list(NETS))
+def test_30_block_logits_loss_and_all_gradients(name, math_mode):
+  ocfg, params, x, cond, logits_ref, loss_ref, grads_ref = _oracle(name)
+  model = _model(name, params)
+  assert model.receptive_field == 3071 and len(model.wavenet_blocks) == 30
+  from wavenets_amd import _lib
+  assert [_lib.lib().wn_plan_dilation(model._plan, b) for b in (0, 9, 10, 29)] == [1, 512, 1, 512]
+  inp = (x[:, :-1].to(dev()), cond.to(dev())) if cond is not None else x[:, :-1].to(dev())
+  lg = model.logits(inp).cpu().double()
+  err = (lg - logits_ref).abs().max().item()
+  assert err < ATOL_ACT, (name, math_mode, 'logits', err)
+  data = (x.to(dev()), cond.to(dev())) if cond is not None else x.to(dev())
+  loss, _, _ = model.loss_and_grads(data)
+  assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item())), (loss[0].item(), loss_ref.item())
+  worst = ('', 0.0)
+  for n, g, r in zip(model.variable_names, model.gradients(), grads_ref):
+    scale = max(r.abs().max().item(), 1e-6)
+    e = (g.cpu().double() - r).abs().max().item()
+    if e / scale > worst[1]:
+      worst = (n, e / scale)
+    assert e < 1e-4 * scale + 1e-7, (name, math_mode, n, e, scale)
+  print(f'{name} [{math_mode}]: logits max|err| {err:.2e}, worst gradient {worst[0]} rel {worst[1]:.2e}')
+
+
+@pytest.mark.parametrize('name', ['configs1_cat_r64', 'configs3_mol10_r128'])
+def test_30_block_probabilities_and_samples(name):
+  """Model output as call() returns it (softmax probabilities / mixture parameters) and the deterministic
+  sample drawn from it (src/model.py:415-418,487-498), 30 blocks deep."""
+  ocfg, params, x, cond, logits_ref, _, _ = _oracle(name)
+  model = _model(name, params)
+  out = model(x[:, :-1].to(dev()))
+  ref = O.model_forward(x[:, :-1].double(), [p.double() for p in params], ocfg)
+  assert (out.cpu().double() - ref).abs().max().item() < ATOL_ACT
+  got = model.sample_waveform(out, deterministic=True).cpu()
+  want = O.sample_waveform_deterministic(ref.float(), ocfg)
+  if ocfg.sampling_function == 'categorical':
+    top2 = torch.topk(ref, 2, dim=-1).values
+    clear = ((top2[..., 0] - top2[..., 1]) > 2e-4).unsqueeze(-1)
+    assert torch.equal(got[clear], want[clear])
+  else:
+    w = torch.softmax(ref[..., :ocfg.num_mixtures], -1)
+    top2 = torch.topk(w, 2, dim=-1).values
+    clear = ((top2[..., 0] - top2[..., 1]) > 1e-3).unsqueeze(-1)
+    assert (got[clear] - want[clear]).abs().max().item() < ATOL_ACT

@@ -1,0 +1,102 @@
+"""The product's data-parallel step under 2 ranks on real hardware (src/model.py:328-336,
+train.py:203-205): WaveNet.train_step on row shards with the one-bucket SUM all-reduce must leave bit-equal
+replicas and equal the single-process step on the concatenated batch.
+
+ * test_two_ranks_one_gpu_gloo: both ranks share cuda:0 and exchange over gloo -- runs on a 1-GPU box, so the HIP
+   path under world_size 2 (bucket layout, loss tail, post-reduce clipnorm, metric mean, per-rank dropout masks)
+   is exercised wherever the GPU tests run;
+ * test_two_ranks_nccl: one rank per GPU over RCCL; skipped when fewer than 2 devices are visible.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(blocks=6, channels=32, skip_channels=64, dilation_bound=8, final_layers_channels=[48, 40],
+          activation='leaky_relu', bits=8, l2_reg_factor=0.001)
+GLOBAL_B, T, STEPS = 4, 300, 3
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _data():
+  from wavenets_amd.data import synthetic_waveforms
+  return synthetic_waveforms(GLOBAL_B, T + 1, seed=99, device='cpu')
+
+
+def _run_steps(model, x):
+  from wavenets_amd import Adam, MeanSquaredError
+  model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0), metrics=[MeanSquaredError()])
+  logs = None
+  for _ in range(STEPS):
+    logs = model.train_step(x)
+  return logs
+
+
+def _worker(rank, world, port, backend, out_dir, dropout):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  dev_index = rank if backend == 'nccl' else 0
+  torch.cuda.set_device(dev_index)
+  dev = torch.device('cuda', dev_index)
+  if backend == 'nccl':
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+  else:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+  from wavenets_amd import WaveNet, dp
+  model = WaveNet(**KW, dropout=dropout, device=dev, seed=7)
+  x = _data()[dp.shard_rows(GLOBAL_B, world, rank)].to(dev)
+  logs = _run_steps(model, x)
+  torch.save({'params': model.flat_params.data.cpu(), 'logs': logs, 'drop_step': model._drop_step},
+             os.path.join(out_dir, f'rank{rank}.pt'))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _check(tmp_path, backend, dropout=0.0):
+  world = 2
+  mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), dropout), nprocs=world, join=True)
+  r0 = torch.load(tmp_path / 'rank0.pt')
+  r1 = torch.load(tmp_path / 'rank1.pt')
+  assert torch.equal(r0['params'], r1['params'])                 # replicas stay bit-identical
+  assert r0['logs']['loss'] == r1['logs']['loss'] and r0['logs']['reg_loss'] == r1['logs']['reg_loss']
+  assert r0['logs']['mean_squared_error'] == r1['logs']['mean_squared_error']      # metric is reduced too
+  return r0
+
+
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_rank_train_step_equals_single_process(tmp_path, backend):
+  if backend == 'nccl' and torch.cuda.device_count() < 2:
+    pytest.skip('needs 2 GPUs')
+  from wavenets_amd import WaveNet
+  r0 = _check(tmp_path, backend)
+  dev = torch.device('cuda', 0)
+  single = WaveNet(**KW, device=dev, seed=7)
+  logs = _run_steps(single, _data().to(dev))
+  err = (single.flat_params.data.cpu() - r0['params']).abs().max().item()
+  assert err < 1e-5, err
+  assert abs(logs['loss'] - r0['logs']['loss']) < 1e-5 * abs(logs['loss'])
+  assert abs(logs['reg_loss'] - r0['logs']['reg_loss']) < 1e-6 * max(1.0, abs(logs['reg_loss']))
+
+
+def test_two_rank_dropout_masks_differ_per_replica(tmp_path):
+  """MirroredStrategy draws an independent Dropout mask on every replica: the mask counter folds the rank in
+  (call_index * world + rank + 1).  Replicas must still agree bit for bit after the reduce."""
+  from wavenets_amd import _lib
+  r0 = _check(tmp_path, 'gloo', dropout=0.2)
+  assert r0['drop_step'] == STEPS
+  L = _lib.lib()
+  keys = {L.wn_dropout_key_for(7, 0, call * 2 + rank + 1) for call in range(STEPS) for rank in range(2)}
+  assert len(keys) == 2 * STEPS

@@ -1,5 +1,7 @@
-"""Full-size checks at BASELINE.json configs[1] (30-layer, 64/256 channels, batch 8 x 16000) where the
-CPU oracle is too slow: size-independent properties of the HIP path.
+"""Full-size checks at BASELINE.json configs[1], configs[3] (30-layer MoL-10 head, 128 residual channels, 16 bits)
+and configs[4] (configs[1] + global conditioning, 110-way one-hot -> mapping [8,16,32]), each at its per-GPU
+shape batch 8 x 16000, where the CPU oracle is too slow: size-independent properties of the HIP path.
+(tests/test_gpu_baseline_nets.py compares the same 30-block networks with the oracle at B = 2, T = 3500.)
 
  * directional derivative: (L(theta + eps v) - L(theta - eps v)) / (2 eps) == <grad, v>
  * batch linearity (the data-parallel contract): grads(A) + grads(B) == grads(A u B) under the
@@ -15,29 +17,58 @@ pytestmark = pytest.mark.gpu
 
 CFG2 = dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024,
             final_layers_channels=[128, 256], activation='leaky_relu', bits=8)
+CFG4 = dict(CFG2, channels=128, num_mixtures=10, sampling_function='logistic', bits=16)
+CFG5 = dict(CFG2, conditioning='global', mapping_layers=[8, 16, 32], mapping_activation='leaky_relu')
+FULL = {'configs1': CFG2, 'configs3_mol_r128': CFG4, 'configs4_globalcond': CFG5}
+N_SPEAKERS = 110
 
 
 def dev():
   return torch.device('cuda', 0)
 
 
-@pytest.fixture(scope='module')
-def setup():
+class _Data:
+  """A batch (waveforms [+ one-hot speaker condition]) that slices like the tensor the tests used to pass."""
+
+  def __init__(self, x, cond=None):
+    self.x, self.cond = x, cond
+
+  def __getitem__(self, idx):
+    rows = idx[0] if isinstance(idx, tuple) else idx
+    return _Data(self.x[idx], self.cond[rows] if self.cond is not None else None)
+
+  @property
+  def arg(self):
+    return (self.x, self.cond) if self.cond is not None else self.x
+
+
+@pytest.fixture(scope='module', params=list(FULL))
+def setup(request):
   from wavenets_amd import WaveNet
   from oracle import wavenet_oracle as O          # synthetic input generator only
-  model = WaveNet(**CFG2, device=dev(), seed=3)
+  kw = FULL[request.param]
+  model = WaveNet(**kw, device=dev(), seed=3)
+  model._test_kw = kw
+  if kw.get('conditioning'):
+    model.build([(1, 8, 1), (1, N_SPEAKERS)])
   g = torch.Generator().manual_seed(0)
   with torch.no_grad():                           # non-zero biases (Keras zeros would hide bias bugs)
     for n, t in zip(model.variable_names, model.trainable_variables):
       if n.endswith('bias'):
         t.copy_(((torch.rand(t.shape, generator=g) * 2 - 1) * 0.05).to(dev()))
   x = O.synthetic_waveform(8, 16001, seed=77).to(dev())
-  return model, x
+  cond = None
+  if kw.get('conditioning'):
+    ids = torch.randint(0, N_SPEAKERS, (8,), generator=torch.Generator().manual_seed(9))
+    cond = torch.nn.functional.one_hot(ids, N_SPEAKERS).float().to(dev())
+  yield model, _Data(x, cond)
+  del model
+  torch.cuda.empty_cache()
 
 
 def test_directional_derivative(setup):
   model, x = setup
-  loss, _, _ = model.loss_and_grads(x)
+  loss, _, _ = model.loss_and_grads(x.arg)
   grads = model.flat_grads.clone()
   g = torch.Generator().manual_seed(1)
   v = torch.randn(grads.numel(), generator=g).to(dev())
@@ -47,7 +78,7 @@ def test_directional_derivative(setup):
   vals = []
   for sgn in (1.0, -1.0):
     model.flat_params.data.copy_(theta + sgn * eps * v)
-    vals.append(model.test_step(x)['loss'])
+    vals.append(model.test_step(x.arg)['loss'])
     model.loss_tracker.reset_state()
   model.flat_params.data.copy_(theta)
   fd = (vals[0] - vals[1]) / (2 * eps)
@@ -58,13 +89,13 @@ def test_directional_derivative(setup):
 
 def test_batch_linearity_and_determinism(setup):
   model, x = setup
-  l_all, _, _ = model.loss_and_grads(x, global_batch=8, n_replicas=1)
+  l_all, _, _ = model.loss_and_grads(x.arg, global_batch=8, n_replicas=1)
   g_all = model.flat_grads.clone()
-  l_again, _, _ = model.loss_and_grads(x, global_batch=8, n_replicas=1)
+  l_again, _, _ = model.loss_and_grads(x.arg, global_batch=8, n_replicas=1)
   assert torch.equal(l_all, l_again) and torch.equal(g_all, model.flat_grads)      # deterministic
   acc, ltot = torch.zeros_like(g_all), 0.0
   for part in (x[:3], x[3:]):
-    l, _, _ = model.loss_and_grads(part, global_batch=8, n_replicas=2)
+    l, _, _ = model.loss_and_grads(part.arg, global_batch=8, n_replicas=2)
     acc += model.flat_grads
     ltot += l[0].item()
   assert abs(ltot - l_all[0].item()) < 1e-5 * abs(l_all[0].item())
@@ -75,7 +106,7 @@ def test_batch_linearity_and_determinism(setup):
 def test_math_modes_agree(setup):
   from wavenets_amd import _lib
   model, x = setup
-  inp = x[:2, :4096]
+  inp = x[:2, :4096].arg
   a = model.logits(inp)
   _lib.lib().wn_debug_set(1, 1)
   try:
@@ -90,19 +121,20 @@ def test_queued_equals_naive_full_receptive_field(setup):
   rf = model.receptive_field
   assert rf == 3071
   w = x[:4, :rf]
-  naive = model.generate(6, sample=w, use_queues=False, deterministic=True)
-  queued = model.generate(6, sample=w, use_queues=True, deterministic=True)
+  naive = model.generate(6, sample=w.x, condition=w.cond, use_queues=False, deterministic=True)
+  queued = model.generate(6, sample=w.x, condition=w.cond, use_queues=True, deterministic=True)
   assert torch.equal(naive, queued)
 
 
 def test_train_steps_reduce_loss(setup):
   from wavenets_amd import Adam, WaveNet
-  _, x = setup
-  model = WaveNet(**CFG2, device=dev(), seed=5)
+  ref_model, x = setup
+  kw = dict(ref_model._test_kw)
+  model = WaveNet(**kw, device=dev(), seed=5)
   model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
-  first = model.train_step(x)['loss']
+  first = model.train_step(x.arg)['loss']
   for _ in range(5):
-    last = model.train_step(x)
+    last = model.train_step(x.arg)
   model.loss_tracker.reset_state()
-  final = model.test_step(x)['loss']
+  final = model.test_step(x.arg)['loss']
   assert final < first and torch.isfinite(torch.tensor(final))

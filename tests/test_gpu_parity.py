@@ -190,6 +190,34 @@ def test_layer_generate_single_step():
   assert (gs[:, 0] - full_s[:, t]).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize('R,D,S,dil,k,cond_c', [(32, 32, 64, 4, 2, 0), (64, 64, 256, 512, 2, 0), (32, 32, None, 1, 2, 0),
+                                                (32, 32, 64, 2, 2, 5), (64, 64, None, 3, 3, 0)])
+def test_layer_generate_matches_oracle(R, D, S, dil, k, cond_c, math_mode):
+  """G3 against the oracle's restatement of src/layers.py:226-290 (not against the layer's own forward)."""
+  layer, ps, dl = _layer_pair(R, D, S, dil, k=k, cond_c=cond_c, seed=2)
+  g = torch.Generator().manual_seed(11)
+  gathered = torch.randn(3, k, R, generator=g) * 0.8
+  cond = torch.randn(3, 1, cond_c, generator=g) if cond_c else None
+  ref_x, ref_s = O.layer_generate(gathered.double(), [p.double() for p in ps], has_skip=S is not None,
+                                  cond=cond.double() if cond is not None else None)
+  with torch.no_grad():
+    gx, gs = layer.generate((gathered.to(dev()), cond.to(dev())) if cond_c else gathered.to(dev()))
+  assert gx.shape == (3, 1, R) and gs.shape == (3, 1, S if S is not None else R)
+  assert (gx.cpu().double() - ref_x).abs().max() < ATOL_ACT
+  assert (gs.cpu().double() - ref_s).abs().max() < ATOL_ACT
+  # and the oracle's single step is the oracle's full forward at that step (the two restatements agree)
+  d = dl[0]
+  x = torch.randn(3, (k - 1) * d + 3, R, generator=g).double()
+  t = x.shape[1] - 1
+  taps = torch.stack([x[:, t - (k - 1 - j) * d] for j in range(k)], dim=1)
+  cfull = cond.double().expand(3, x.shape[1], cond_c) if cond_c else None
+  fx, fs = O.layer_forward(x, [p.double() for p in ps], dilations=dl, activation_name=None, residual=True,
+                           has_skip=S is not None, cond=cfull)
+  sx, ss = O.layer_generate(taps, [p.double() for p in ps], has_skip=S is not None,
+                            cond=cond.double() if cond is not None else None)
+  assert (sx[:, 0] - fx[:, t]).abs().max() < 1e-12 and (ss[:, 0] - fs[:, t]).abs().max() < 1e-12
+
+
 def test_layer_errors():
   from wavenets_amd import WaveNetLayer
   l = WaveNetLayer(channels=32, device=dev())
@@ -400,6 +428,68 @@ def test_mixture_loss_fn_and_samplers(name):
   assert torch.equal(s.cpu(), O.sample_waveform_deterministic(pred, ocfg))
   r = model.sample_waveform(pred.to(dev()), deterministic=False)
   assert r.shape == (2, 50, 1) and r.abs().max() <= 1.0
+
+
+@pytest.mark.parametrize('name', ['mol', 'gauss'])
+def test_mixture_stochastic_sampler_distribution(name):
+  """S1, non-deterministic mixture draws (src/model.py:423-443, 463-483): the empirical CDF of n draws from one
+  prediction row against the analytic law (component ~ softmax(w); mu + e^s * logistic / normal noise; clipped to
+  [-1, 1]).  Dvoretzky-Kiefer-Wolfowitz: P(sup|F_n - F| > eps) <= 2 exp(-2 n eps^2) = 1.1e-6 at these sizes."""
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=4, **kw)
+  M = kw['num_mixtures']
+  g = torch.Generator().manual_seed(3)
+  row = torch.cat([torch.randn(M, generator=g), torch.rand(M, generator=g) * 1.6 - 0.8,
+                   torch.rand(M, generator=g) * 3.0 - 4.0])          # scales e^-4 .. e^-1: both atoms get mass
+  n = 200000
+  eps = math.sqrt(math.log(2 / 1.1e-6) / (2 * n))
+  big = row.expand(1, n, 3 * M).contiguous()
+  draws = model.sample_waveform(big.to(dev()), deterministic=False).cpu().reshape(-1).double()
+  assert draws.abs().max() <= 1.0
+  v = torch.linspace(-1.0, 0.9999, 400, dtype=torch.float64)
+  Fn = (draws.unsqueeze(0) <= v.unsqueeze(1)).double().mean(1)
+  F = O.mixture_sample_cdf(row, ocfg, v)
+  assert (Fn - F).abs().max().item() < eps, (Fn - F).abs().max().item()
+  # the component pick follows softmax(w): with tiny scales every draw sits on its component's mean
+  tight = torch.cat([row[:M], row[M:2 * M], torch.full((M,), -12.0)])
+  d2 = model.sample_waveform(tight.expand(1, n, 3 * M).contiguous().to(dev()), deterministic=False).cpu().reshape(-1)
+  comp = (d2.unsqueeze(1) - row[M:2 * M].unsqueeze(0)).abs().argmin(1)
+  counts = torch.bincount(comp, minlength=M).double()
+  w = torch.softmax(row[:M].double(), -1)
+  chi2 = (((counts - n * w) ** 2) / (n * w)).sum().item()
+  assert chi2 < 70.0, chi2                                # M-1 <= 9 dof: P(chi2 > 70) < 1e-10
+  # a second call draws a different stream (per-call offset), rows within a call are not all alike
+  d3 = model.sample_waveform(big.to(dev()), deterministic=False).cpu().reshape(-1).double()
+  assert not torch.equal(d3, draws) and draws.unique().numel() > n // 4
+
+
+def test_weights_io_round_trip_with_optimizer_state(tmp_path):
+  """train.py:149-154,237-238 convention: save -> load into a fresh model restores weights (+ Adam moments and
+  step, which the reference drops) so that the next training step is bit-identical."""
+  from wavenets_amd import WaveNet, Adam, io
+  kw = dict(MODEL_CASES['cat_small_fused'])
+  x, _ = _inputs(kw, 2, 200, seed=5)
+  a = WaveNet(**kw, device=dev(), seed=1)
+  a.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
+  for _ in range(3):
+    a.train_step(x.to(dev()))
+  path = str(tmp_path / io.checkpoint_name(3, 5e-4))
+  io.save_weights(a, path, optimizer=a.optimizer)
+  b = WaveNet(**kw, device=dev(), seed=2)
+  b.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
+  assert not torch.equal(a.flat_params.data, b.flat_params.data)
+  io.load_weights(b, path, optimizer=b.optimizer)
+  assert torch.equal(a.flat_params.data, b.flat_params.data)
+  assert b.optimizer.iterations == a.optimizer.iterations == 3
+  assert torch.equal(a.optimizer.m, b.optimizer.m) and torch.equal(a.optimizer.v, b.optimizer.v)
+  la, lb = a.train_step(x.to(dev())), b.train_step(x.to(dev()))
+  assert torch.equal(a.flat_params.data, b.flat_params.data)
+  assert io.find_resume(str(tmp_path))[1:] == (3, 5e-4)
+  # weights only (what the reference stores): the moments restart from zero
+  c = WaveNet(**kw, device=dev(), seed=3)
+  io.load_weights(c, path)
+  with np.load(path) as d:
+    assert all(np.array_equal(w, d[f'w{i:03d}']) for i, w in enumerate(c.get_weights()))
 
 
 def test_categorical_samplers():

@@ -35,10 +35,49 @@ def test_preprocess_filters_invalid_frames():
 def test_checkpoint_naming_and_resume(tmp_path):
   assert io.checkpoint_name(7, 0.0005) == 'weights-e0007-lr0.0005.weights.npz'
   assert io.find_resume(str(tmp_path / 'missing')) is None
+  import numpy as np
   for e, lr in ((1, 0.0005), (12, 0.0001), (3, 0.0005)):
-    (tmp_path / io.checkpoint_name(e, lr)).write_bytes(b'')
+    np.savez(str(tmp_path / io.checkpoint_name(e, lr)), names=np.array(['causal/kernel']))
+  # a write that was killed half-way sorts last but does not open: resume must skip it, not crash
+  (tmp_path / io.checkpoint_name(13, 0.0001)).write_bytes(b'PK\x03\x04 truncated')
+  (tmp_path / io.checkpoint_name(14, 0.0001)).write_bytes(b'')
   f, epoch, lr = io.find_resume(str(tmp_path))
   assert os.path.basename(f) == 'weights-e0012-lr0.0001.weights.npz' and epoch == 12 and lr == 0.0001
+
+
+class _FakeModel:
+  variable_names = ['causal/kernel', 'causal/bias']
+  dropout = 0.1
+  _drop_step = 41
+
+  def __init__(self):
+    import numpy as np
+    self.w = [np.arange(6, dtype=np.float32).reshape(2, 1, 3), np.ones(3, np.float32)]
+
+  def get_weights(self):
+    return [w.copy() for w in self.w]
+
+  def set_weights(self, ws):
+    self.w = [w.copy() for w in ws]
+
+  def set_drop_step(self, n):
+    self._drop_step = n
+
+
+def test_save_weights_is_atomic_and_round_trips(tmp_path):
+  import numpy as np
+  a, b = _FakeModel(), _FakeModel()
+  b.w = [w * 0 for w in b.w]
+  b._drop_step = 0
+  path = str(tmp_path / io.checkpoint_name(2, 0.0005))
+  io.save_weights(a, path)
+  assert sorted(os.listdir(tmp_path)) == [io.checkpoint_name(2, 0.0005)]       # no temp file left behind
+  io.load_weights(b, path)
+  assert all(np.array_equal(x, y) for x, y in zip(a.w, b.w)) and b._drop_step == 41
+  b.variable_names = ['other']
+  import pytest
+  with pytest.raises(ValueError):
+    io.load_weights(b, path)
 
 
 class _Opt:

@@ -104,6 +104,10 @@ struct wn_plan {
   bool phase_on = false;
   int prof_used = 0;
   bool prof_on = false;
+  // wn_stack_prof_enable: event pairs around the whole residual-block stack forward (first block launch -> end of
+  // the folded skip contraction): SURVEY.md 8(d)'s t_stack_fwd
+  std::vector<hipEvent_t> stack_ev;
+  int stack_used = 0;
 };
 
 namespace {
@@ -950,6 +954,7 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_tdesc) (void)hipFree(p->d_tdesc);
   if (p->d_kdesc) (void)hipFree(p->d_kdesc);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->stack_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->phase_ev) if (e) (void)hipEventDestroy(e);
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
@@ -986,6 +991,33 @@ extern "C" int wn_prof_enable(wn_plan* p, int32_t max_launches) {
     WN_HIP_CHECK(hipEventCreate(&e));
     p->prof_ev.push_back(e);
   }
+  return WN_OK;
+}
+// ---- the whole block stack: one event pair per forward pass, first block launch -> end of the folded skip sum ----
+extern "C" int wn_stack_prof_enable(wn_plan* p, int32_t max_passes) {
+  if (!p) return WN_E_INVALID;
+  for (hipEvent_t e : p->stack_ev) (void)hipEventDestroy(e);
+  p->stack_ev.clear();
+  p->stack_used = 0;
+  for (int i = 0; i < 2 * max_passes; ++i) {
+    hipEvent_t e;
+    WN_HIP_CHECK(hipEventCreate(&e));
+    p->stack_ev.push_back(e);
+  }
+  return WN_OK;
+}
+extern "C" int wn_stack_prof_read(wn_plan* p, int32_t* passes, float* avg_ms) {
+  if (!p || !passes || !avg_ms) return WN_E_INVALID;
+  double tot = 0.0;
+  int n = 0;
+  for (int i = 0; i + 1 < p->stack_used; i += 2) {
+    float ms = 0.f;
+    WN_HIP_CHECK(hipEventElapsedTime(&ms, p->stack_ev[i], p->stack_ev[i + 1]));
+    tot += ms; ++n;
+  }
+  *passes = n;
+  *avg_ms = n ? (float)(tot / n) : 0.f;
+  p->stack_used = 0;
   return WN_OK;
 }
 // ---- phase marks of wn_train_fwd_bwd (bench.py): events after the forward, the loss, the backward-data
@@ -1192,6 +1224,8 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   // profiling: is the chain N back-to-back launches of the fused block kernel?
   const bool prof_chain = p->prof_on && !rings && p->LPB == 1 && p->c.cond_inputs == 0 && p->R == p->D &&
                           !(training && p->drop_rate > 0.f) && block_ptrs(p, 0, params, fragbase, B, T).fused;
+  const bool stack_prof = !rings && p->stack_used + 2 <= (int)p->stack_ev.size();
+  if (stack_prof) (void)hipEventRecord(p->stack_ev[p->stack_used], s);
   for (int b = 0; b < p->N; ++b) {
     BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
     if (p->c.cond_inputs > 0) k.cb = ws + L.cb + (int64_t)b * B * 2 * p->D;
@@ -1245,6 +1279,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   } else {
     hin = ws + L.H[training ? p->N : (p->N & 1)];
   }
+  if (stack_prof) { (void)hipEventRecord(p->stack_ev[p->stack_used + 1], s); p->stack_used += 2; }
   // head, src/model.py:105-119,237-238: conv -> activation, last conv linear (softmax applied later)
   int hc = p->Hin;
   for (size_t i = 0; i < p->finals.size(); ++i) {
@@ -1463,6 +1498,7 @@ extern "C" int wn_eval_loss(wn_plan* p, const float* params, const float* x_full
   float* inputs = workspace + L.probs;
   hipLaunchKernelGGL(wn_shift_split_kernel, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 4096)), dim3(256), 0, s,
                      x_full, B, T, inputs, workspace + L.yt);
+  WN_HIP_CHECK(hipGetLastError());
   int rc = forward_core(p, params, inputs, true, cond, B, T, false, workspace, L, s);
   if (rc) return rc;
   rc = loss_stage(p, B, T, global_batch > 0 ? global_batch : B, false, workspace, L, loss_out, nullptr, s);
@@ -1484,12 +1520,12 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   if (ws_floats < L.total) { wn_set_error("train_fwd_bwd: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)L.total); return WN_E_INVALID; }
   if (global_batch <= 0) global_batch = B;
   if (n_replicas <= 0) n_replicas = 1;
-  p->drop_step += 1;                                   // a fresh dropout mask per training step
   float* ws = workspace;
   const int64_t rows = (int64_t)B * T;
   float* inputs = ws + L.probs;
   hipLaunchKernelGGL(wn_shift_split_kernel, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 4096)), dim3(256), 0, s,
                      x_full, B, T, inputs, ws + L.yt);
+  WN_HIP_CHECK(hipGetLastError());
   if (p->phase_on) (void)hipEventRecord(p->phase_ev[0], s);
   int rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
   if (rc) return rc;
@@ -1640,9 +1676,20 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       WN_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
       WN_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     }
+    // Whatever happens after the fork, the caller's stream must not run ahead of the side stream's kernels (they
+    // read and write the workspace and the gradient slab): an early error return joins through this guard.
+    struct SideJoin {
+      wn_plan* p; hipStream_t s; bool armed;
+      ~SideJoin() {
+        if (!armed) return;
+        if (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)
+          (void)hipStreamSynchronize(p->side);
+      }
+    } side_join{p, s, false};
     if (fork) {
       WN_HIP_CHECK(hipEventRecord(p->ev_fork, s));
       WN_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+      side_join.armed = true;
     }
     const bool head_own = L.hsplits > 0 && p->head_first < p->njobs;
     rc = wn_launch_wgrad_batched(p->d_jobs, head_own ? p->head_first : p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits,
@@ -1675,7 +1722,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
                                 p->tensors[b0.conv_skip.bias_t].off, bst, p->N, am_gskip, s);
       if (rc) return rc;
     }
-    if (fork) WN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0));
+    if (fork) { WN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0)); side_join.armed = false; }
     if (cond_batched) {
       const int D2 = 2 * p->D;
       const BlockInfo& b0 = p->blocks[0];

@@ -29,7 +29,19 @@ def save_weights(model, path: str, optimizer=None) -> None:
     arrays['adam_m'] = optimizer.m.detach().cpu().numpy()
     arrays['adam_v'] = optimizer.v.detach().cpu().numpy()
     arrays['adam_iterations'] = np.int64(optimizer.iterations)
-  np.savez(path, **arrays)
+  if getattr(model, 'dropout', 0) > 0:
+    arrays['drop_step'] = np.int64(getattr(model, '_drop_step', 0))
+  # write beside the target and rename: a kill mid-write must not leave a truncated file that sorts last and
+  # is then picked by find_resume (the temp name does not match the checkpoint pattern)
+  tmp = os.path.join(os.path.dirname(os.path.abspath(path)), f'.tmp-{os.getpid()}-' + os.path.basename(path))
+  if not tmp.endswith('.npz'):
+    tmp += '.npz'                     # np.savez appends .npz otherwise
+  try:
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path if path.endswith('.npz') else path + '.npz')
+  finally:
+    if os.path.exists(tmp):
+      os.remove(tmp)
 
 
 def load_weights(model, path: str, optimizer=None) -> None:
@@ -43,6 +55,8 @@ def load_weights(model, path: str, optimizer=None) -> None:
       optimizer.m.copy_(torch.from_numpy(d['adam_m']).to(optimizer.m.device))
       optimizer.v.copy_(torch.from_numpy(d['adam_v']).to(optimizer.v.device))
       optimizer.iterations = int(d['adam_iterations'])
+    if 'drop_step' in d and hasattr(model, 'set_drop_step'):
+      model.set_drop_step(int(d['drop_step']))
 
 
 def find_resume(run_dir: str) -> Optional[Tuple[str, int, float]]:
@@ -50,7 +64,13 @@ def find_resume(run_dir: str) -> Optional[Tuple[str, int, float]]:
   if not os.path.isdir(run_dir):
     return None
   files = sorted(f for f in os.listdir(run_dir) if _NAME.search(f))
-  if not files:
-    return None
-  m = _NAME.search(files[-1])
-  return os.path.join(run_dir, files[-1]), int(m.group(1)), float(m.group(2))
+  for name in reversed(files):          # newest first; a file that does not open (truncated write) is skipped
+    full = os.path.join(run_dir, name)
+    try:
+      with np.load(full, allow_pickle=False) as d:
+        d['names']
+    except Exception:                   # zipfile.BadZipFile, OSError, KeyError, ValueError ...
+      continue
+    m = _NAME.search(name)
+    return full, int(m.group(1)), float(m.group(2))
+  return None

@@ -133,6 +133,7 @@ class WaveNet(torch.nn.Module):
     self.loss_tracker = _Mean('loss')
     self.reg_loss = _Mean('reg_loss') if self.regularization else None
     self._sample_calls = 0
+    self._drop_step = 0                   # training calls made so far (dropout mask counter; saved by io.save_weights)
     self._fused_step_sample = True        # train_step draws its metric sample inside the library
     # structure handles (attribute names of the reference)
     dil = s.dilations
@@ -350,6 +351,34 @@ class WaveNet(torch.nn.Module):
       return dist.get_world_size()
     return 1
 
+  @staticmethod
+  def _rank():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+      return dist.get_rank()
+    return 0
+
+  def _replica_mean(self, values):
+    """Metric values are means over this replica's rows; Keras aggregates them over the replicas (equal shares)."""
+    world = self._world()
+    if world > 1:
+      import torch.distributed as dist
+      dist.all_reduce(values, op=dist.ReduceOp.SUM)
+      values = values / world
+    return values
+
+  def set_drop_step(self, n: int):
+    """Training calls already made (resume): the next dropout mask is that of call n + 1."""
+    self._drop_step = int(n)
+
+  def _arm_dropout(self):
+    # every replica draws its own mask each step (MirroredStrategy runs an independent Dropout per replica):
+    # mask counter = call_index * world + rank + 1; single process: 1, 2, 3, ...
+    if self.dropout > 0:
+      step = self._drop_step * self._world() + self._rank() + 1
+      _lib.check(_lib.lib().wn_plan_set_dropout(self._plan, self.dropout, self._seed, step))
+      self._drop_step += 1
+
   def loss_and_grads(self, data, global_batch=None, n_replicas=None, want_pred=False, want_sample=False,
                      _loss_in_bucket=False):
     """Forward + loss + backward of this replica's rows (src/model.py:319-335).
@@ -382,6 +411,7 @@ class WaveNet(torch.nn.Module):
         sample = None
     want_pred = want_pred or (want_sample and sample is None)
     pred = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device) if want_pred else None
+    self._arm_dropout()
     try:
       _lib.check(L.wn_train_fwd_bwd(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
                                     int(global_batch), int(n_replicas), _lib.ptr(self.flat_grads),
@@ -406,7 +436,8 @@ class WaveNet(torch.nn.Module):
     # metrics that can reduce on the device do so behind the optimizer; ONE read brings back loss, reg_loss and them
     pending = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
                if hasattr(m, 'update_state_device')]
-    lv = (torch.cat([loss] + [v for _, v in pending]) if pending else loss).tolist()
+    mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
+    lv = (torch.cat([loss, mv]) if pending else loss).tolist()
     for (m, _), v in zip(pending, lv[2:]):
       m.commit(v)
     for metric in self.metrics:
@@ -439,7 +470,8 @@ class WaveNet(torch.nn.Module):
     # as in train_step: device-side metric reductions first, then ONE device-to-host read
     pending = [(m, m.update_state_device(x[:, 1:, :], sample)) for m in self._metrics_from_compilation
                if hasattr(m, 'update_state_device')]
-    lv = (torch.cat([loss] + [v for _, v in pending]) if pending else loss).tolist()
+    mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
+    lv = (torch.cat([loss, mv]) if pending else loss).tolist()
     for (m, _), v in zip(pending, lv[2:]):
       m.commit(v)
     for metric in self.metrics:
