@@ -105,6 +105,12 @@ uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* t
 int wn_debug_set(int key, int value);     /* tuning knobs for tools/ scripts */
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
 int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
+/* test / diagnosis hook: float offset and length, inside the caller's TRAINING workspace for (B, T), of an
+ * intermediate the last wn_train_fwd_bwd left there (deferred weight-gradient layout, layers_per_block = 1).
+ * what: 0 H[idx] | 1 Z[idx] | 2 saved sigmoid[idx] | 3 skip sum | 4 head activation[idx] | 5 logits |
+ *       6 dL/d(final[idx] pre-activation) | 7 dL/d(skip sum) | 8 dL/du[idx] | 9 dL/dH[idx] | 10 max-abs slots */
+int wn_debug_ws_region(const wn_plan* p, int32_t B, int32_t T, int32_t what, int32_t idx, int64_t* off,
+                       int64_t* len);
 /* the whole residual-block stack of a forward pass: one event pair per pass from the first block launch to
  * the end of the folded skip contraction = t_stack_fwd of SURVEY.md 8(d); read returns passes and the average */
 int wn_stack_prof_enable(wn_plan* p, int32_t max_passes);

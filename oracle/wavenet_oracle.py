@@ -179,6 +179,24 @@ def activation(x: torch.Tensor, name: Optional[str]) -> torch.Tensor:
   raise NotImplementedError(name)
 
 
+KINK_TOL = 1e-4   # = the per-activation tolerance of north_star: inside it the branch of a kinked activation is undecided
+
+
+def activation_with_branch(x: torch.Tensor, name: Optional[str], branch_pos: Optional[torch.Tensor]):
+  """``activation`` for gradient comparisons through relu / leaky_relu.  Their derivative jumps at 0, so where a
+  pre-activation lies within KINK_TOL of the kink an implementation that is accurate to the stated tolerance may
+  legitimately sit on either side.  ``branch_pos`` (bool, same shape) says which side the implementation under
+  test took (post-activation >= 0 / > 0); it is used ONLY for those undecided elements, every other element takes
+  the branch of its own sign.  Returns (y, number of elements decided by branch_pos)."""
+  if branch_pos is None or name not in ('relu', 'leaky_relu'):
+    return activation(x, name), 0
+  own = (x >= 0) if name == 'leaky_relu' else (x > 0)
+  near = x.detach().abs() < KINK_TOL
+  pos = torch.where(near, branch_pos.to(torch.bool), own)
+  slope = LEAKY_SLOPE if name == 'leaky_relu' else 0.0
+  return torch.where(pos, x, x * slope), int((near & (pos != own)).sum())
+
+
 def causal_conv1d(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor,
                   dilation: int = 1) -> torch.Tensor:
   """Keras Conv1D(padding='causal'): left zero-pad d*(k-1), VALID dilated correlation.
@@ -336,7 +354,8 @@ def mapping_forward(cond: torch.Tensor, params: Sequence[torch.Tensor],
 
 def model_forward(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleConfig,
                   cond: Optional[torch.Tensor] = None, return_logits: bool = False,
-                  return_intermediates: bool = False, dropout: Optional[Tuple[float, int, int]] = None):
+                  return_intermediates: bool = False, dropout: Optional[Tuple[float, int, int]] = None,
+                  head_branch: Optional[Sequence[torch.Tensor]] = None):
   """WaveNet.call, src/model.py:213-239.  x: (B,T,1); cond: (B, cond_inputs) or None.
 
   Returns probabilities for the categorical head (softmax activation on the last conv,
@@ -372,9 +391,14 @@ def model_forward(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleCo
       h = h + sk                                           # src/model.py:235-236
   inter['skip_sum'] = h
   nf = len(cfg.final_layers_channels)
+  inter['head_pre'], inter['kink_overrides'] = [], 0
   for i in range(nf):
     fk, fb = cur.take(2)
-    h = activation(conv1x1(h, fk, fb), cfg.activation)     # src/model.py:105-111
+    a = conv1x1(h, fk, fb)
+    inter['head_pre'].append(a)
+    # src/model.py:105-111 (head_branch: see activation_with_branch -- gradient comparisons only)
+    h, nov = activation_with_branch(a, cfg.activation, head_branch[i] if head_branch is not None else None)
+    inter['kink_overrides'] += nov
   fk, fb = cur.take(2)
   logits = conv1x1(h, fk, fb)
   inter['logits'] = logits
@@ -532,7 +556,8 @@ def l2_penalty(params: Sequence[torch.Tensor], cfg: OracleConfig) -> torch.Tenso
 
 def loss_and_grads(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleConfig,
                    cond: Optional[torch.Tensor] = None, global_batch: Optional[int] = None,
-                   n_replicas: int = 1, dropout: Optional[Tuple[float, int, int]] = None):
+                   n_replicas: int = 1, dropout: Optional[Tuple[float, int, int]] = None,
+                   head_branch: Optional[Sequence[torch.Tensor]] = None):
   """Forward + loss + reverse-mode gradients of one replica's share of a train step.
 
   x: (B, T+1, 1).  inputs = x[:, :-1], target = prepare_target(x[:, 1:]) (src/model.py:
@@ -543,7 +568,7 @@ def loss_and_grads(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleC
   ps = [p.detach().clone().requires_grad_(True) for p in params]
   inputs, y_true = x[:, :-1, :], x[:, 1:, :]
   target = prepare_target(y_true, cfg)
-  pred = model_forward(inputs, ps, cfg, cond, dropout=dropout)
+  pred = model_forward(inputs, ps, cfg, cond, dropout=dropout, head_branch=head_branch)
   per = loss_fn(target, pred, cfg)                  # (B,T)
   Bg = x.shape[0] if global_batch is None else global_batch
   loss = per.sum() / Bg

@@ -40,7 +40,7 @@ _ORACLE = {}
 
 
 def _oracle(name):
-  """fp64 oracle results of one network, computed once for both math modes."""
+  """Inputs and fp64 oracle forward of one network, computed once for both math modes."""
   if name in _ORACLE:
     return _ORACLE[name]
   kw = dict(NETS[name])
@@ -56,9 +56,25 @@ def _oracle(name):
   cd = cond.double() if cond is not None else None
   torch.set_num_threads(16)
   _, inter = O.model_forward(x[:, :-1].double(), pd, ocfg, cd, return_intermediates=True)
-  loss, _, grads, _ = O.loss_and_grads(x.double(), pd, ocfg, cd)
-  _ORACLE[name] = (ocfg, params, x, cond, inter['logits'], loss, grads)
+  _ORACLE[name] = (ocfg, params, x, cond, inter)
   return _ORACLE[name]
+
+
+def _oracle_grads(name, head_branch):
+  """fp64 loss and gradients (parameters, skip sum, every block input).  ``head_branch``: the side of the
+  leaky_relu kink the product took for each head activation -- used by the oracle only where its own
+  pre-activation is within 1e-4 of the kink (O.activation_with_branch): a 30-block net at this size has a few
+  such elements in every run, and there the derivative (1 vs 0.2) is undecided within the activation tolerance."""
+  ocfg, params, x, cond, _ = _oracle(name)
+  ps = [p.double().requires_grad_(True) for p in params]
+  cd = cond.double() if cond is not None else None
+  pred, inter = O.model_forward(x[:, :-1].double(), ps, ocfg, cd, return_intermediates=True, head_branch=head_branch)
+  target = O.prepare_target(x[:, 1:].double(), ocfg)
+  loss = O.loss_fn(target, pred, ocfg).sum() / B
+  want = [inter['skip_sum']] + inter['h'][:-1]            # nothing flows into the last block output (skip head)
+  gr = torch.autograd.grad(loss, ps + want, allow_unused=True)
+  grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(gr[:len(ps)], ps)]
+  return loss.detach(), grads, gr[len(ps)], gr[len(ps) + 1:], inter['kink_overrides']
 
 
 @pytest.fixture(params=['split', 'fp32'])
@@ -81,19 +97,42 @@ def _model(name, params):
 
 
 @pytest.mark.parametrize('name', list(NETS))
-def test_30_block_logits_loss_and_all_gradients(name, math_mode):
-  ocfg, params, x, cond, logits_ref, loss_ref, grads_ref = _oracle(name)
+def test_30_block_activations_loss_and_all_gradients(name, math_mode):
+  from wavenets_amd import _lib
+  ocfg, params, x, cond, inter = _oracle(name)
   model = _model(name, params)
   assert model.receptive_field == 3071 and len(model.wavenet_blocks) == 30
-  from wavenets_amd import _lib
   assert [_lib.lib().wn_plan_dilation(model._plan, b) for b in (0, 9, 10, 29)] == [1, 512, 1, 512]
   inp = (x[:, :-1].to(dev()), cond.to(dev())) if cond is not None else x[:, :-1].to(dev())
   lg = model.logits(inp).cpu().double()
-  err = (lg - logits_ref).abs().max().item()
+  err = (lg - inter['logits']).abs().max().item()
   assert err < ATOL_ACT, (name, math_mode, 'logits', err)
   data = (x.to(dev()), cond.to(dev())) if cond is not None else x.to(dev())
   loss, _, _ = model.loss_and_grads(data)
+  torch.cuda.synchronize()
+
+  def ws(what, idx, shape):
+    return model.training_intermediate(what, idx, B, T).cpu().double().reshape(shape)
+
+  # ---- every activation the training pass keeps: block inputs H[0..30], skip sum, head activations ----
+  worst_act = 0.0
+  for b, h in enumerate(inter['h']):
+    worst_act = max(worst_act, (ws(0, b, h.shape) - h).abs().max().item())
+    assert worst_act < ATOL_ACT, (name, math_mode, f'H[{b}]', worst_act)
+  assert (ws(3, 0, inter['skip_sum'].shape) - inter['skip_sum']).abs().max().item() < ATOL_ACT
+  branch = []
+  for i, a in enumerate(inter['head_pre']):
+    ha = ws(4, i, a.shape)
+    assert (ha - O.activation(a, ocfg.activation)).abs().max().item() < ATOL_ACT, (name, f'head activation {i}')
+    branch.append(ha >= 0)                               # leaky_relu: the product's side of the kink
+  # ---- loss, data gradients at the skip sum and at every block input, every parameter gradient ----
+  loss_ref, grads_ref, g_skip_ref, g_h_ref, n_kink = _oracle_grads(name, branch)
   assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item())), (loss[0].item(), loss_ref.item())
+  e = (ws(7, 0, g_skip_ref.shape) - g_skip_ref).abs().max().item()
+  assert e < 1e-4 * g_skip_ref.abs().max().item(), (name, math_mode, 'd loss / d skip sum', e)
+  for b, r in enumerate(g_h_ref):
+    e = (ws(9, b, r.shape) - r).abs().max().item()
+    assert e < 1e-4 * r.abs().max().item(), (name, math_mode, f'd loss / d H[{b}]', e)
   worst = ('', 0.0)
   for n, g, r in zip(model.variable_names, model.gradients(), grads_ref):
     scale = max(r.abs().max().item(), 1e-6)
@@ -101,14 +140,15 @@ def test_30_block_logits_loss_and_all_gradients(name, math_mode):
     if e / scale > worst[1]:
       worst = (n, e / scale)
     assert e < 1e-4 * scale + 1e-7, (name, math_mode, n, e, scale)
-  print(f'{name} [{math_mode}]: logits max|err| {err:.2e}, worst gradient {worst[0]} rel {worst[1]:.2e}')
+  print(f'{name} [{math_mode}]: logits max|err| {err:.2e}, block inputs max|err| {worst_act:.2e}, worst gradient '
+        f'{worst[0]} rel {worst[1]:.2e}, {n_kink} leaky_relu kink decisions taken from the product')
 
 
 @pytest.mark.parametrize('name', ['configs1_cat_r64', 'configs3_mol10_r128'])
 def test_30_block_probabilities_and_samples(name):
   """Model output as call() returns it (softmax probabilities / mixture parameters) and the deterministic
   sample drawn from it (src/model.py:415-418,487-498), 30 blocks deep."""
-  ocfg, params, x, cond, logits_ref, _, _ = _oracle(name)
+  ocfg, params, x, cond, _ = _oracle(name)
   model = _model(name, params)
   out = model(x[:, :-1].to(dev()))
   ref = O.model_forward(x[:, :-1].double(), [p.double() for p in params], ocfg)

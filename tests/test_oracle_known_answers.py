@@ -245,3 +245,19 @@ def test_global_conditioning_is_a_per_batch_bias():
   assert torch.equal(out, out2)
   # different condition -> different output
   assert not torch.allclose(out, O.model_forward(x, params, cfg, cond + 1.0))
+
+
+def test_activation_with_branch_only_decides_inside_the_kink_tolerance():
+  """O.activation_with_branch: the implementation's branch is taken only where |pre-activation| < KINK_TOL."""
+  x = torch.tensor([-1.0, -5e-5, 5e-5, 0.0, 2.0, -2e-4, 3e-4], dtype=torch.float64, requires_grad=True)
+  all_pos = torch.ones(7, dtype=torch.bool)
+  y, n = O.activation_with_branch(x, 'leaky_relu', all_pos)
+  g, = torch.autograd.grad(y.sum(), x)
+  assert g.tolist() == [0.2, 1.0, 1.0, 1.0, 1.0, 0.2, 1.0] and n == 1          # only -5e-5 changed side
+  y, n = O.activation_with_branch(x, 'leaky_relu', ~all_pos)
+  g, = torch.autograd.grad(y.sum(), x)
+  assert g.tolist() == [0.2, 0.2, 0.2, 0.2, 1.0, 0.2, 1.0] and n == 2
+  y0, n0 = O.activation_with_branch(x, 'leaky_relu', None)
+  assert n0 == 0 and torch.equal(y0, O.activation(x, 'leaky_relu'))
+  yt, nt = O.activation_with_branch(x, 'tanh', all_pos)                          # smooth activations: untouched
+  assert nt == 0 and torch.equal(yt, torch.tanh(x))

@@ -73,6 +73,8 @@ _SIGS = {
     'wn_dropout_key_for': (C.c_uint32, [C.c_uint64, C.c_int32, C.c_uint64]),
     'wn_prof_enable': (C.c_int, [_P, C.c_int32]),
     'wn_prof_read': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    'wn_debug_ws_region': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64)]),
     'wn_stack_prof_enable': (C.c_int, [_P, C.c_int32]),
     'wn_stack_prof_read': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     'wn_phase_enable': (C.c_int, [_P, C.c_int32]),

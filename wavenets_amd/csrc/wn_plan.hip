@@ -1077,6 +1077,36 @@ extern "C" int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t
   return make_layout(p, B, T, training != 0).total;
 }
 
+// test / diagnosis hook: where a training call keeps an intermediate in the caller's workspace (float offset and
+// length), so that parity tests can compare saved activations and data gradients with the oracle's.
+//   what: 0 block input H[idx] (idx 0..N) | 1 gated activations Z of block idx | 2 saved sigmoid of block idx |
+//         3 skip sum | 4 head activation idx | 5 logits | 6 d loss / d (final layer idx output, pre-activation) |
+//         7 d loss / d skip sum | 8 d loss / d u of block idx ([rows][2D]) | 9 d loss / d H[idx] | 10 running max-abs slots
+extern "C" int wn_debug_ws_region(const wn_plan* p, int32_t B, int32_t T, int32_t what, int32_t idx, int64_t* off,
+                                  int64_t* len) {
+  if (!p || !off || !len || B < 1 || T < 1) return WN_E_INVALID;
+  const WsLayout L = make_layout(p, B, T, true);
+  const int64_t rows = (int64_t)B * T;
+  auto in = [&](size_t n) { return idx >= 0 && (size_t)idx < n; };
+  *off = -1; *len = 0;
+  switch (what) {
+    case 0: if (in(L.H.size())) { *off = L.H[idx]; *len = rows * p->R; } break;
+    case 1: if (in((size_t)p->N)) { *off = L.Z + (int64_t)idx * rows * p->Dp; *len = rows * p->Dp; } break;
+    case 2: if (in(L.AG.size())) { *off = L.AG[idx]; *len = rows * p->D; } break;
+    case 3: *off = L.skipsum; *len = rows * p->Hin; break;
+    case 4: if (in(L.HA.size())) { *off = L.HA[idx]; *len = rows * p->finals[idx].cout; } break;
+    case 5: *off = L.logits; *len = rows * p->Cout; break;
+    case 6: if (in(L.GF.size())) { *off = L.GF[idx]; *len = rows * p->finals[idx].cout; } break;
+    case 7: *off = L.g_skipsum; *len = rows * p->Hin; break;
+    case 8: if (in(L.GU.size())) { *off = L.GU[idx]; *len = rows * 2 * p->D; } break;
+    case 9: if (in(L.GH.size())) { *off = L.GH[idx]; *len = rows * p->R; } break;
+    case 10: *off = L.absmax; *len = L.n_absmax; break;
+    default: break;
+  }
+  if (*off < 0) { wn_set_error("ws_region: no such region (%d, %d)", what, idx); return WN_E_INVALID; }
+  return WN_OK;
+}
+
 // ==========================================================================================
 // model forward / backward
 // ==========================================================================================

@@ -358,6 +358,13 @@ class WaveNet(torch.nn.Module):
       return dist.get_rank()
     return 0
 
+  def training_intermediate(self, what: int, idx: int, B: int, T: int):
+    """View on an intermediate the last loss_and_grads call (B utterances, T predicted samples) left in the
+    training workspace (wn_debug_ws_region; parity tests compare these with the oracle's autograd values)."""
+    off, ln = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib().wn_debug_ws_region(self._plan, B, T, what, idx, C.byref(off), C.byref(ln)))
+    return self._ws['train'][off.value:off.value + ln.value]
+
   def _replica_mean(self, values):
     """Metric values are means over this replica's rows; Keras aggregates them over the replicas (equal shares)."""
     world = self._world()
