@@ -127,6 +127,12 @@ int wn_forward(wn_plan* p, const float* params, const float* x, const float* con
                int32_t T, float* out, float* logits_out, float* workspace, int64_t ws_floats,
                void* stream);
 
+/* WaveNet.call(inputs, training=True): the same forward with the Dropout layers active (src/layers.py:195-196),
+ * mask of the step last set by wn_plan_set_dropout; workspace sized for training (wn_plan_workspace_floats(.., 1)) */
+int wn_forward_training(wn_plan* p, const float* params, const float* x, const float* cond, int32_t B,
+                        int32_t T, float* out, float* logits_out, float* workspace, int64_t ws_floats,
+                        void* stream);
+
 /* ---- gradient half of WaveNet.train_step, src/model.py:319-335 ----
  * x_full (B,T+1,1): inputs = x[:, :-1], targets = prepare_target(x[:, 1:]).
  * loss = sum_{b,t} l / global_batch (+ l2 * sum W^2 / n_replicas).  grads receives

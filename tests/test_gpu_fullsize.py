@@ -116,6 +116,24 @@ def test_math_modes_agree(setup):
   assert (a - b).abs().max().item() < 1e-4
 
 
+def test_folded_skip_sum_kernel_forms_agree_bitwise(setup):
+  """The folded skip sum (src/model.py:235-236 as ONE K = N_blocks * D contraction) runs on the 256-column wide kernel
+  at this size and on two 128-column blocks of the streamed kernel otherwise (knob 12), with the same per-element
+  MFMA sequence: the logits at the full 8 x 16000 shape must be bit-identical (the oracle comparison of the
+  contraction itself runs at small sizes, where only the 128-column form applies)."""
+  from wavenets_amd import _lib
+  model, x = setup
+  inp = x[:, :16000].arg
+  L = _lib.lib()
+  ref = model.logits(inp).clone()
+  try:
+    L.wn_debug_set(12, 1)
+    other = model.logits(inp)
+  finally:
+    L.wn_debug_set(12, 0)
+  assert torch.equal(ref, other) and torch.isfinite(ref).all()
+
+
 def test_queued_equals_naive_full_receptive_field(setup):
   model, x = setup
   rf = model.receptive_field

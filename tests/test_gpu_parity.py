@@ -643,6 +643,31 @@ def test_dropout_training_step_parity(name, math_mode):
   assert (model(x[:, :-1].to(dev())).cpu().double() - ref).abs().max() < ATOL_ACT
 
 
+def test_call_training_true_applies_dropout(math_mode):
+  """WaveNet.call(inputs, training=True) (src/model.py:233 -> src/layers.py:195-196): a stochastic forward whose mask
+  is that of the model's next training call; the oracle restates the mask hash."""
+  from wavenets_amd import WaveNet
+  kw = dict(MODEL_CASES['cat_small_fused'])
+  rate, seed = 0.3, 5
+  ocfg = O.OracleConfig(**kw)
+  params = O.init_params(ocfg, seed=2)
+  model = WaveNet(**kw, dropout=rate, device=dev(), seed=seed)
+  model.set_weights([p.numpy() for p in params])
+  x, _ = _inputs(kw, 2, 200, seed=4)
+  pd = [p.double() for p in params]
+  for step in (1, 2):
+    got = model(x.to(dev()), training=True)
+    ref = O.model_forward(x.double(), pd, ocfg, dropout=(rate, seed, step))
+    assert (got.cpu().double() - ref).abs().max() < ATOL_ACT, step
+  plain = O.model_forward(x.double(), pd, ocfg)
+  assert (ref - plain).abs().max() > 1e-4                      # the mask does something (probabilities are ~4e-3)
+  assert (model(x.to(dev())).cpu().double() - plain).abs().max() < ATOL_ACT       # training=False: no dropout
+  # a training step after two stochastic forwards uses mask number 3
+  loss_ref, _, _, _ = O.loss_and_grads(torch.cat([x, x[:, :1]], 1).double(), pd, ocfg, dropout=(rate, seed, 3))
+  loss, _, _ = model.loss_and_grads(torch.cat([x, x[:, :1]], 1).to(dev()))
+  assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item()))
+
+
 def test_layer_dropout_training_mode():
   from wavenets_amd import WaveNetLayer
   layer = WaveNetLayer(channels=32, skip_channels=32, dilation_rate=2, dropout=0.5, device=dev())

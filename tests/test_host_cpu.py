@@ -154,3 +154,17 @@ def test_sound_callback_argument_checks():
     SoundCallback('x', 16000, 10, True, use_fast='maybe')
   with pytest.raises(ValueError, match='epoch_frequency'):
     SoundCallback('x', 16000, 10, True, epoch_frequency=0)
+
+
+def test_condition_frames_follow_the_utterance_label():
+  """src/utils.py:42-50: every frame of an utterance carries its one-hot class; the validity filter drops frames, and
+  their condition rows with them."""
+  import torch
+  x = torch.linspace(-0.9, 0.9, 1000)
+  x[450] = 1.5                                       # one frame leaves [-1, 1] -> filtered out
+  frames, cond = data.preprocess_with_condition(x, 2, 4, 99, False)
+  assert frames.shape == (9, 100, 1) and cond.shape == (9, 4)
+  assert torch.equal(cond, torch.tensor([0.0, 0.0, 1.0, 0.0]).expand(9, 4))
+  import pytest
+  with pytest.raises(ValueError):
+    data.preprocess_with_condition(x, 4, 4, 99, False)

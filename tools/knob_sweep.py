@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from wavenets_amd import WaveNet, Adam, _lib
 from wavenets_amd.data import synthetic_waveforms

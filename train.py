@@ -6,8 +6,11 @@
 
 Keys are the reference's (including the misspelt ``use_resiudal``); ``dataset`` is either
 ``synthetic`` (default: SURVEY.md 8d two-tone generator) or a ``.npy`` file of shape (n, samples)
-with waveforms in [-1, 1] (int16 arrays are divided by 2**15).  Checkpoints follow the
-reference's ``weights-e{epoch:04d}-lr{lr}`` naming and resume-from-filename convention."""
+with waveforms in [-1, 1] (int16 arrays are divided by 2**15).  With ``conditioning: global`` every utterance
+carries a class id (``labels``: a ``.npy`` of n integers; synthetic data: utterance index modulo ``condition_classes``)
+that becomes a one-hot condition on each of its frames, as the reference does with the speaker's gender
+(src/utils.py:46-49, train.py:98-124); batches are then ``(frames, condition)`` tuples (src/model.py:315-317).
+Checkpoints follow the reference's ``weights-e{epoch:04d}-lr{lr}`` naming and resume-from-filename convention."""
 import argparse
 import os
 import sys
@@ -28,7 +31,7 @@ config = {                       # defaults of the reference, train.py:22-50
     'final_layers_channels': [128, 256], 'l2_reg_factor': 0,
     # additions of this driver
     'steps_per_epoch': 0, 'synthetic_utterances': 256, 'sample_rate': 16000, 'results_dir': './results',
-    'preview_length': 0,
+    'preview_length': 0, 'condition_classes': 2, 'labels': None,
 }
 
 
@@ -58,9 +61,9 @@ def main():
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group('nccl', device_id=dev)
-  if config['conditioning'] is not None:
-    raise SystemExit('this driver trains unconditioned models; pass (x, cond) tuples to WaveNet.train_step for '
-                     'global conditioning')
+  conditioned = config['conditioning'] is not None
+  if conditioned and config['conditioning'] != 'global':
+    raise SystemExit("only conditioning: global is supported (local conditioning is broken in the reference, src/model.py:136-137)")
 
   # ---- data: waveforms -> frames of recording_length + 1 (src/utils.py:22-85) ----
   L = int(config['recording_length'])
@@ -71,7 +74,17 @@ def main():
     arr = np.load(config['dataset'])
     raw = torch.from_numpy(arr)
     raw = (data.normalise_int16(raw) if arr.dtype == np.int16 else raw.float()).to(dev)
-  frames = torch.cat([data.preprocess_waveform(w, L, config['apply_mulaw']) for w in raw], dim=0)
+  cond = None
+  if conditioned:
+    ncls = int(config['condition_classes'])
+    labels = np.load(config['labels']).astype(np.int64) if config['labels'] else np.arange(raw.shape[0]) % ncls
+    if len(labels) != raw.shape[0]:
+      raise SystemExit('labels must hold one class id per utterance')
+    parts = [data.preprocess_with_condition(w, int(l), ncls, L, config['apply_mulaw']) for w, l in zip(raw, labels)]
+    frames = torch.cat([p[0] for p in parts], dim=0)
+    cond = torch.cat([p[1] for p in parts], dim=0)
+  else:
+    frames = torch.cat([data.preprocess_waveform(w, L, config['apply_mulaw']) for w in raw], dim=0)
   per_rank = config['batch_size'] // world
   if per_rank < 1 or frames.shape[0] < config['batch_size']:
     raise SystemExit('not enough data for one global batch')
@@ -80,7 +93,7 @@ def main():
 
   model = WaveNet(kernel_size=config['kernel_size'], channels=config['channels'], blocks=config['blocks'],
                   layers_per_block=config['layers_per_block'], activation=config['activation'],
-                  conditioning=None, mapping_layers=config['mapping_layers'],
+                  conditioning=config['conditioning'], mapping_layers=config['mapping_layers'],
                   mapping_activation=config['mapping_activation'], dropout=config['dropout'],
                   dilation_bound=config['dilation_bound'], num_mixtures=config['num_mixtures'],
                   sampling_function=config['sampling_function'], bits=config['bits'],
@@ -88,6 +101,8 @@ def main():
                   use_residual=config['use_resiudal'], use_skip=config['use_skip'],
                   final_layers_channels=config['final_layers_channels'], l2_reg_factor=config['l2_reg_factor'],
                   device=dev)
+  if conditioned:                                                  # Keras builds on the first call (train.py:232-235):
+    model.build([(per_rank, L, 1), (per_rank, cond.shape[1])])    # the condition width fixes the mapping net's shapes
   opt = Adam(learning_rate=config['lr'], clipnorm=1.0)           # train.py:225-226
   model.compile(optimizer=opt, metrics=[MeanSquaredError()])          # train.py:225-228
   print('Receptive field') if rank == 0 else None
@@ -121,7 +136,8 @@ def main():
     stop = False
     for i in range(n_batches):
       idx = perm[i * config['batch_size']:(i + 1) * config['batch_size']][rank * per_rank:(rank + 1) * per_rank]
-      logs = model.train_step(frames[idx.to(dev)])
+      idx = idx.to(dev)
+      logs = model.train_step((frames[idx], cond[idx]) if conditioned else frames[idx])
       if nan_guard.on_batch_end(logs['loss']):
         print('loss is not finite: terminating') if rank == 0 else None
         stop = True
@@ -143,7 +159,9 @@ def main():
   preview = int(config['preview_length']) or 4 * L
   if rank == 0:
     tic = time.time()
-    samples = model.generate(preview, batch_size=min(config['batch_size'], 8), use_queues=config['layers_per_block'] == 1)
+    nprev = min(config['batch_size'], 8)
+    samples = model.generate(preview, batch_size=nprev, condition=cond[:nprev] if conditioned else None,
+                             use_queues=config['layers_per_block'] == 1)
     torch.cuda.synchronize()
     tictoc = time.time() - tic
     print(f'Generation took {tictoc}s')

@@ -80,6 +80,7 @@ _SIGS = {
     'wn_phase_enable': (C.c_int, [_P, C.c_int32]),
     'wn_phase_read': (C.c_int, [_P, C.POINTER(C.c_float)]),
     'wn_forward': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    'wn_forward_training': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
     'wn_train_fwd_bwd': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
                                    _P, C.c_int64, _P]),
     'wn_eval_loss': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),

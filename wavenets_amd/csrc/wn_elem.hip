@@ -939,6 +939,70 @@ int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int 
   return WN_OK;
 }
 
+// Weight gradients of the input causal conv (src/model.py:84-88: C_in = 1, KS taps):
+//   dW[tap][c] = sum_{b,t} x[b][t - (KS-1-tap)] * g[b][t][c],   db[c] = sum_{b,t} g[b][t][c]
+// i.e. KS + 1 weighted column sums of the gradient at the first block input.  On the generic job table the K = 1
+// product ran as a handful of single-wave jobs (0.76 ms at configs[1] for 33 MB of operands); here one workgroup
+// per (utterance, time range) streams its rows of g once with 16-byte loads -- lanes = 4-channel groups x row
+// lanes -- and leaves its partial sums in the split's slab row (flat-gradient layout), like every other weight
+// gradient.  Plain fp32 arithmetic.
+template <int KS>
+__global__ __launch_bounds__(256) void wn_inconv_wgrad_kernel(const float* x, const float* g, int T, int R, int spb,
+                                                              float* slab, int64_t P, int64_t w_off, int64_t b_off) {
+  __shared__ float red[256 * (KS + 1) * 4];
+  const int split = blockIdx.x, ub = split / spb, sp = split % spb;
+  int len = (T + spb - 1) / spb;
+  const int r0 = sp * len, r1 = min(T, r0 + len);
+  const int ng = R / 4, nrl = 256 / ng;                 // 4-channel groups, row lanes
+  const int cg = threadIdx.x % ng, rl = threadIdx.x / ng;
+  float acc[KS + 1][4];
+#pragma unroll
+  for (int i = 0; i <= KS; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  const float* xb = x + (int64_t)ub * T;
+  const float* gb = g + (int64_t)ub * T * R + 4 * cg;
+  for (int t = r0 + rl; t < r1; t += nrl) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + (int64_t)t * R);
+    const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap) {
+      const int ts = t - (KS - 1 - tap);
+      const float xv = ts >= 0 ? xb[ts] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[tap][e] = fmaf(xv, ge[e], acc[tap][e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[KS][e] += ge[e];
+  }
+#pragma unroll
+  for (int i = 0; i <= KS; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(i * 4 + e) * 256 + rl * ng + cg] = acc[i][e];
+  __syncthreads();
+  // (KS + 1) * R outputs, each the sum over the row lanes
+  float* row = slab + (int64_t)split * P;
+  for (int o = threadIdx.x; o < (KS + 1) * R; o += 256) {
+    const int i = o / R, c = o % R;
+    float sum = 0.f;
+    for (int l = 0; l < nrl; ++l) sum += red[(i * 4 + (c & 3)) * 256 + l * ng + (c >> 2)];
+    if (i < KS) row[w_off + (int64_t)i * R + c] = sum;
+    else row[b_off + c] = sum;
+  }
+}
+
+int wn_inconv_wgrad_supported(int R, int KS) { return (R % 4 == 0 && R >= 4 && R <= 1024 && 256 % (R / 4) == 0 && (KS == 2 || KS == 3)) ? 1 : 0; }
+
+int wn_launch_inconv_wgrad(const float* x, const float* g, int B, int T, int R, int KS, int splits_per_b, float* slab,
+                           int64_t P, int64_t w_off, int64_t b_off, hipStream_t s) {
+  if (!wn_inconv_wgrad_supported(R, KS)) { wn_set_error("inconv_wgrad: unsupported shape R=%d KS=%d", R, KS); return WN_E_UNSUPPORTED; }
+  const dim3 grid((unsigned)(B * splits_per_b));
+  if (KS == 2) hipLaunchKernelGGL(wn_inconv_wgrad_kernel<2>, grid, dim3(256), 0, s, x, g, T, R, splits_per_b, slab, P, w_off, b_off);
+  else hipLaunchKernelGGL(wn_inconv_wgrad_kernel<3>, grid, dim3(256), 0, s, x, g, T, R, splits_per_b, slab, P, w_off, b_off);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
 // Queued generation, categorical head, deterministic: softmax -> arg max -> sample value -> output row and
 // next network input, in ONE launch.  The arithmetic per row is that of wn_softmax_kernel followed by
 // wn_sample_det_cat_kernel (same lane assignment, same reductions), so the result is the same sample.

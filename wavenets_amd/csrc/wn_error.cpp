@@ -30,10 +30,12 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   13  = 1: 128-channel per-block weight gradients on the generic job table (no wn_wgrad_pair_kernel)
 //   14  = 1: global conditioning per block (no single contraction over all blocks)
 //   15  = 1: last block's backward without the (zero) output gradient: one-segment product on the fp32 kernel
-static int g_wn_debug[16] = {0};
-int wn_debug_get(int key) { return (key >= 0 && key < 16) ? g_wn_debug[key] : 0; }
+//   19  = 1: head layers' weight gradients on the generic job table (no staged pair jobs)
+//   20  = 1: input conv's weight gradients on the generic job table (no dedicated reduction kernel)
+static int g_wn_debug[32] = {0};
+int wn_debug_get(int key) { return (key >= 0 && key < 32) ? g_wn_debug[key] : 0; }
 extern "C" int wn_debug_set(int key, int value) {
-  if (key < 0 || key >= 16) return -1;
+  if (key < 0 || key >= 32) return -1;
   g_wn_debug[key] = value;
   return 0;
 }

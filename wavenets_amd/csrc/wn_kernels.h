@@ -210,6 +210,10 @@ int wn_launch_cond_gather(const float* slab, int64_t P, int spb, int64_t bd_off0
                           float* dcb, hipStream_t s);
 int wn_launch_cond_wgrad(const float* m, const float* dcb, int B, int Cc, int N, int D2, float* grads, int64_t w_off0,
                          int64_t w_stride, int64_t b_off0, int64_t b_stride, hipStream_t s);
+// dW, db of the input causal conv into the batched weight-gradient slab (wn_elem.hip)
+int wn_inconv_wgrad_supported(int R, int KS);
+int wn_launch_inconv_wgrad(const float* x, const float* g, int B, int T, int R, int KS, int splits_per_b, float* slab,
+                           int64_t P, int64_t w_off, int64_t b_off, hipStream_t s);
 int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int B, int T, int R, int KS, float* y,
                          hipStream_t s);
 int wn_launch_gen_tail_cat_det(const float* logits, int rows, int C, int bits, float* out, int length, int step,

@@ -91,6 +91,10 @@ struct wn_plan {
   WnWgPair* d_pairs = nullptr;
   int pair_first[3] = {0, 0, 0}, pair_count[3] = {0, 0, 0};
   bool jobs_pairk = false;
+  // the head layers' weight gradients as staged pair jobs (kinds 1..4) on the head's own time split
+  int hpair_first[6] = {0, 0, 0, 0, 0, 0}, hpair_count[6] = {0, 0, 0, 0, 0, 0};
+  bool jobs_headpairs = false;
+  bool jobs_inconvk = false;    // input conv's dW / db from the dedicated reduction kernel, not from jobs
   // side stream: the low-occupancy generic weight-gradient jobs overlap the per-block / skip kernels
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -249,6 +253,9 @@ struct WsLayout {
   // the head's weight gradients get their own, finer time split: a compact slab [B*hsplits][head_span] over the
   // contiguous parameter range of the final layers (head_base = its first float); 0 splits = share bslab
   int64_t hslab; int hsplits; int64_t head_base, head_span;
+  // the input conv's (KS + 1) * R sums have a compact slab of their own too: [B * isplits][(KS + 1) * R] (its kernel
+  // and bias are the first two tensors of the flat buffer), so that the 33 MB stream is spread over ~512 workgroups
+  int64_t islab; int isplits;
   int64_t GZS;                          // [rows][N*D] precomputed W_s g_skip of every block, or 0
   std::vector<int64_t> XD;              // dropout: dropped copy of every block input (training)
   int64_t gxd;                          // dropout: scratch for d loss / d (dropped input)
@@ -282,6 +289,15 @@ int count_jobs(const wn_plan* p) {
   }
   for (const ConvInfo& c : p->finals) n += jobs_for(c.cin, c.cout);
   return n;
+}
+
+// the head layers' weight gradients run as staged pair jobs when every final layer has a pair kind (widths 128 / 256)
+// in split-precision mode; knob 19 = 1 keeps them on the generic job table
+bool head_pairs_ok(const wn_plan* p) {
+  if (p->finals.empty() || wn_debug_get(1) == 1 || wn_debug_get(3) == 1 || wn_debug_get(19) == 1) return false;
+  for (const ConvInfo& c : p->finals)
+    if (wn_wgrad_pair_kind(c.cin, c.cout) == 0) return false;
+  return true;
 }
 
 WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
@@ -363,6 +379,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     L.slab = cv.take(need);
     L.bslab = 0; L.bsplits = 0;
     L.hslab = 0; L.hsplits = 0; L.head_base = 0; L.head_span = 0;
+    L.islab = 0; L.isplits = 0;
     if (deferred_wgrad(p)) {
       for (int b = 0; b < p->N; ++b) L.GU.push_back(cv.take(rows * 2 * p->D));
       for (int b = 0; b <= p->N; ++b) L.GH.push_back(cv.take(rows * p->R));
@@ -376,6 +393,11 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
       if (wn_debug_get(10) > 0) sp = std::max(1, std::min(wn_debug_get(10), maxsp));   // knob 10: time splits per utterance
       L.bsplits = sp;
       L.bslab = cv.take((int64_t)B * sp * p->nparams);
+      if (wn_inconv_wgrad_supported(p->R, p->KS) && p->tensors[p->causal.kernel_t].off == 0 &&
+          p->tensors[p->causal.bias_t].off == (int64_t)p->KS * p->R) {
+        L.isplits = std::max(1, std::min((512 + B - 1) / B, std::max(1, T / 64)));
+        L.islab = cv.take((int64_t)B * L.isplits * (p->KS + 1) * p->R);
+      }
       // The head's few products (4-8 jobs each) cannot fill the chip at the blocks' split count (one wave per
       // SIMD with one chunk of look-ahead is latency bound): ~1.5 waves per SIMD for them.  Measured at
       // configs[1] (same-process sweep, ms per step): shared 7.64 | 8 splits 7.68 | 12: 7.57 | 16: 7.71 |
@@ -385,6 +407,8 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
         int njh = 0;
         for (const ConvInfo& c : p->finals) njh += jobs_for(c.cin, c.cout);
         int hs = (int)((1536 + (int64_t)njh * B - 1) / ((int64_t)njh * B));
+        // pair jobs: one workgroup per (layer, utterance, time range) -> about one workgroup per CU and layer
+        if (head_pairs_ok(p)) hs = std::max(1, (256 + B - 1) / B);
         if (wn_debug_get(0) > 0) hs = wn_debug_get(0);
         hs = std::max(sp, std::min(hs, maxsp));
         if (hs > sp) {
@@ -399,6 +423,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
   } else {
     L.bslab = 0; L.bsplits = 0;
     L.hslab = 0; L.hsplits = 0; L.head_base = 0; L.head_span = 0;
+    L.islab = 0; L.isplits = 0;
     L.g_a = L.g_b = L.g_skipsum = L.g_h0 = L.g_h1 = L.g_o = L.g_p = L.slab = 0;
     L.slab_floats = 0;
   }
@@ -1388,11 +1413,15 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool pairk = !layerk && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
                      wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
                      wn_debug_get(13) != 1;
+  const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
+  // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
+  const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk) return WN_OK;
+      p->jobs_pairk == pairk && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk) return WN_OK;
   std::vector<WnWgLayer> wgl;
   std::vector<WnWgPair> pairs[3];
+  std::vector<WnWgPair> hpairs[6];
   std::vector<WnWgJob> jobs;
   std::vector<WnTensorDesc> cov;
   auto cover = [&](int t) { WnTensorDesc d; d.off = p->tensors[t].off; d.len = p->tensors[t].len; cov.push_back(d); };
@@ -1402,10 +1431,11 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   auto am_GU = [&](int b) { return L.absmax + nfin + 1 + b; };
   auto am_GH = [&](int b) { return L.absmax + nfin + 1 + p->N + b; };
   // input causal conv: x = inputs (B,T,1), g = d loss / d H[0]
-  for (int t = 0; t < p->KS; ++t)
-    add_jobs(jobs, L.probs, 1, 1, p->KS - 1 - t, L.GH[0], p->R, p->R,
-             p->tensors[p->causal.kernel_t].off + (int64_t)t * p->R,
-             t == p->KS - 1 ? p->tensors[p->causal.bias_t].off : -1, am_GH(0));
+  if (!inconvk)
+    for (int t = 0; t < p->KS; ++t)
+      add_jobs(jobs, L.probs, 1, 1, p->KS - 1 - t, L.GH[0], p->R, p->R,
+               p->tensors[p->causal.kernel_t].off + (int64_t)t * p->R,
+               t == p->KS - 1 ? p->tensors[p->causal.bias_t].off : -1, am_GH(0));
   cover(p->causal.kernel_t); cover(p->causal.bias_t);
   for (int b = 0; b < p->N; ++b) {
     const BlockInfo& bi = p->blocks[b];
@@ -1461,14 +1491,28 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   for (size_t i = 0; i < p->finals.size(); ++i) {
     const ConvInfo& c = p->finals[i];
     const int64_t xin = (i == 0) ? (p->c.use_skip ? L.skipsum : L.H[p->N]) : L.HA[i - 1];
-    add_jobs(jobs, xin, c.cin, c.cin, 0, L.GF[i], c.cout, c.cout, p->tensors[c.kernel_t].off,
-             p->tensors[c.bias_t].off, L.absmax + (int64_t)i);
+    if (headpairs) {
+      WnWgPair w;
+      memset(&w, 0, sizeof(w));
+      w.x_off = xin; w.g_off = L.GF[i]; w.shift = 0;
+      w.w_off = p->tensors[c.kernel_t].off; w.b_off = p->tensors[c.bias_t].off;
+      w.gmax_off = L.absmax + (int64_t)i;
+      const int kind = wn_wgrad_pair_kind(c.cin, c.cout);
+      hpairs[kind].push_back(w);
+      if (kind == 5) {                     // second 128-column half
+        w.g_off += 128; w.w_off += 128; w.b_off += 128;
+        hpairs[kind].push_back(w);
+      }
+    } else {
+      add_jobs(jobs, xin, c.cin, c.cin, 0, L.GF[i], c.cout, c.cout, p->tensors[c.kernel_t].off,
+               p->tensors[c.bias_t].off, L.absmax + (int64_t)i);
+    }
     cover(c.kernel_t); cover(c.bias_t);
   }
   if (p->d_jobs) { (void)hipFree(p->d_jobs); p->d_jobs = nullptr; }
   if (p->d_cov) { (void)hipFree(p->d_cov); p->d_cov = nullptr; }
-  WN_HIP_CHECK(hipMalloc((void**)&p->d_jobs, jobs.size() * sizeof(WnWgJob)));
-  WN_HIP_CHECK(hipMemcpy(p->d_jobs, jobs.data(), jobs.size() * sizeof(WnWgJob), hipMemcpyHostToDevice));
+  WN_HIP_CHECK(hipMalloc((void**)&p->d_jobs, std::max<size_t>(jobs.size(), 1) * sizeof(WnWgJob)));
+  if (!jobs.empty()) WN_HIP_CHECK(hipMemcpy(p->d_jobs, jobs.data(), jobs.size() * sizeof(WnWgJob), hipMemcpyHostToDevice));
   WN_HIP_CHECK(hipMalloc((void**)&p->d_cov, cov.size() * sizeof(WnTensorDesc)));
   WN_HIP_CHECK(hipMemcpy(p->d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
   if (p->d_wgl) { (void)hipFree(p->d_wgl); p->d_wgl = nullptr; }
@@ -1484,12 +1528,17 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       p->pair_count[kd] = (int)pairs[kd].size();
       all.insert(all.end(), pairs[kd].begin(), pairs[kd].end());
     }
+    for (int kd = 1; kd <= 5; ++kd) {
+      p->hpair_first[kd] = (int)all.size();
+      p->hpair_count[kd] = (int)hpairs[kd].size();
+      all.insert(all.end(), hpairs[kd].begin(), hpairs[kd].end());
+    }
     if (!all.empty()) {
       WN_HIP_CHECK(hipMalloc((void**)&p->d_pairs, all.size() * sizeof(WnWgPair)));
       WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk;
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
   p->jobs_skipk = skipk;
@@ -1506,6 +1555,26 @@ extern "C" int wn_forward(wn_plan* p, const float* params, const float* x, const
   const WsLayout L = make_layout(p, B, T, false);
   if (ws_floats < L.total) { wn_set_error("forward: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)L.total); return WN_E_INVALID; }
   int rc = forward_core(p, params, x, true, cond, B, T, false, workspace, L, s);
+  if (rc) return rc;
+  const int64_t rows = (int64_t)B * T;
+  if (logits_out) WN_HIP_CHECK(hipMemcpyAsync(logits_out, workspace + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (out) {
+    if (p->c.head == WN_HEAD_CATEGORICAL) return wn_launch_softmax(workspace + L.logits, out, rows, p->Cout, s);
+    WN_HIP_CHECK(hipMemcpyAsync(out, workspace + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return WN_OK;
+}
+
+// WaveNet.call(inputs, training=True), src/model.py:213-239 with src/layers.py:195-196: the forward pass with the
+// Dropout layers active (the mask of the step set by wn_plan_set_dropout).  Needs the TRAINING workspace size.
+extern "C" int wn_forward_training(wn_plan* p, const float* params, const float* x, const float* cond, int32_t B,
+                                   int32_t T, float* out, float* logits_out, float* workspace, int64_t ws_floats,
+                                   void* stream) {
+  if (!p || !params || !x || !workspace || B < 1 || T < 1) { wn_set_error("forward_training: bad arguments"); return WN_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  const WsLayout L = make_layout(p, B, T, true);
+  if (ws_floats < L.total) { wn_set_error("forward_training: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)L.total); return WN_E_INVALID; }
+  int rc = forward_core(p, params, x, true, cond, B, T, true, workspace, L, s);
   if (rc) return rc;
   const int64_t rows = (int64_t)B * T;
   if (logits_out) WN_HIP_CHECK(hipMemcpyAsync(logits_out, workspace + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1641,9 +1710,10 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       if (rc) return rc;
     }
     // W_s g_skip of every block in ONE contraction: each block then reads its D-column slice (33 MB at
-    // configs[1]) instead of re-reading g_skip (131 MB).  Measured SLOWER on configs[1] (12.6 vs 12.0 ms
-    // per step: the 1920-column product and the strided slice reads cost more than the re-reads save),
-    // so it is opt-in (knob 4 = 1).
+    // configs[1]) instead of re-reading g_skip (131 MB).  Measured SLOWER on configs[1] (round 1: 12.6 vs 12.0 ms
+    // per step; round 2, also with a block-major [N][rows][D] result so that the slices are contiguous: 8.59 vs
+    // 7.68 ms -- the K = 256, N = 1920 product costs ~1.5 ms, far more than the re-reads it saves), so it is
+    // opt-in (knob 4 = 1).
     bool have_gzs = false;
     if (L.GZS > 0 && p->frag16_gzs >= 0 && wn_debug_get(1) != 1 && wn_debug_get(4) == 1) {
       Gemm gz(B, T, p->N * p->D, p->N * p->D / 32);
@@ -1721,16 +1791,30 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       WN_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
       side_join.armed = true;
     }
-    const bool head_own = L.hsplits > 0 && p->head_first < p->njobs;
+    if (p->jobs_inconvk) {
+      rc = wn_launch_inconv_wgrad(inputs, ws + L.GH[0], B, T, p->R, p->KS, L.isplits, ws + L.islab, (int64_t)(p->KS + 1) * p->R,
+                                  0, (int64_t)p->KS * p->R, fork ? p->side : s);
+      if (rc) return rc;
+    }
+    const bool head_own = L.hsplits > 0 && (p->head_first < p->njobs || p->jobs_headpairs);
     rc = wn_launch_wgrad_batched(p->d_jobs, head_own ? p->head_first : p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits,
                                  fork ? p->side : s);
     if (rc) return rc;
     if (head_own) {
       // job and coverage offsets are offsets into the flat parameter buffer: the compact slab is addressed
       // through a base shifted by -head_base with the head span as its row pitch
-      rc = wn_launch_wgrad_batched(p->d_jobs + p->head_first, p->njobs - p->head_first, ws, ws + L.hslab - L.head_base,
-                                   L.head_span, B, T, L.hsplits, fork ? p->side : s);
-      if (rc) return rc;
+      if (p->head_first < p->njobs) {
+        rc = wn_launch_wgrad_batched(p->d_jobs + p->head_first, p->njobs - p->head_first, ws, ws + L.hslab - L.head_base,
+                                     L.head_span, B, T, L.hsplits, fork ? p->side : s);
+        if (rc) return rc;
+      }
+      if (p->jobs_headpairs)
+        for (int kd = 1; kd <= 5; ++kd)
+          if (p->hpair_count[kd] > 0) {
+            rc = wn_launch_wgrad_pairs(kd, p->d_pairs + p->hpair_first[kd], p->hpair_count[kd], ws, ws + L.hslab - L.head_base,
+                                       L.head_span, B, T, L.hsplits, fork ? p->side : s);
+            if (rc) return rc;
+          }
     }
     if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
     for (int kd = 1; kd <= 2; ++kd)
@@ -1768,8 +1852,15 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
                                 p->tensors[b0.conv_cond.bias_t].off, bst, s);
       if (rc) return rc;
     }
-    rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov, head_own ? p->cov_head_first : p->ncov, s);
+    // coverage entries 0, 1 are the input conv's kernel and bias: from their compact slab when the dedicated kernel ran
+    const int cov0 = p->jobs_inconvk ? 2 : 0;
+    rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov + cov0,
+                                (head_own ? p->cov_head_first : p->ncov) - cov0, s);
     if (rc) return rc;
+    if (p->jobs_inconvk) {
+      rc = wn_launch_reduce_table(ws + L.islab, B * L.isplits, (int64_t)(p->KS + 1) * p->R, grads, p->d_cov, 2, s);
+      if (rc) return rc;
+    }
     if (head_own) {
       rc = wn_launch_reduce_table(ws + L.hslab - L.head_base, B * L.hsplits, L.head_span, grads, p->d_cov + p->cov_head_first,
                                   p->ncov - p->cov_head_first, s);

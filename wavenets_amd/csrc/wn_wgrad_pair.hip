@@ -10,15 +10,16 @@
 //
 // Used for the per-block gradients of widths the one-workgroup-per-block kernel (wn_wgrad_layer.hip:
 // R = D = 32 / 64) does not cover -- configs[3], R = D = 128: three jobs per block (two taps of dW_d, dW_r),
-// ~5000 workgroups per step.  It is NOT used for the head layers: with only ~100-900 workgroups it ran
-// no faster than the generic job table beside the other weight-gradient kernels.
+// ~5000 workgroups per step -- and (round 2) for head layers of widths 128 / 256 on their own time split: one
+// workgroup per (layer, utterance, 1/32 of the utterance) = 256 workgroups per layer computing the WHOLE K x N
+// product of their rows, so every operand row is read exactly once.
 #include <hip/hip_fp16.h>
 
 #include "wn_kernels.h"
 
 typedef _Float16 wp_h8 __attribute__((ext_vector_type(8)));
 
-template <int LDX, int LDG, int KT, int NT>
+template <int LDX, int LDG, int KT, int NT, int LDW = 32 * NT>
 __global__ __launch_bounds__(64 * (KT / 2) * (NT / 2)) void wn_wgrad_pair_kernel(const WnWgPair* jobs, float* ws, float* slab,
                                                                                 int64_t P, int B, int T, int spb) {
   constexpr int KC = 32 * KT, NC = 32 * NT, NCH = KC + NC;
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(64 * (KT / 2) * (NT / 2)) void wn_wgrad_pair_kernel
   float* row = slab + (int64_t)split * P;
 #pragma unroll
   for (int i = 0; i < TK; ++i) {
-    float* tbase = row + J.w_off + (int64_t)(32 * (wk * TK + i)) * NC + tl;
+    float* tbase = row + J.w_off + (int64_t)(32 * (wk * TK + i)) * LDW + tl;      // LDW: row pitch of dW (>= the tile's NC)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tbase[wn_drow(r, h) * NC + 32 * (wn * TN + j)] = acc[i][j][r] * inv;
+      for (int r = 0; r < 16; ++r) tbase[wn_drow(r, h) * LDW + 32 * (wn * TN + j)] = acc[i][j][r] * inv;
   }
   if (J.b_off >= 0) {                                    // bias sums: the two halves of a chunk live in different threads
     if (gunit) bpart[hg * NC + cg] = bsum;
@@ -172,10 +173,14 @@ __global__ __launch_bounds__(64 * (KT / 2) * (NT / 2)) void wn_wgrad_pair_kernel
   }
 }
 
-// kind 1: X 128 ch x G 256 ch (a tap of dW_d at R = D = 128); kind 2: 128 x 128 (dW_r)
+// kind 1: X 128 ch x G 256 ch (a tap of dW_d at R = D = 128; a 128 -> 256 head layer); kind 2: 128 x 128 (dW_r);
+// kind 3: 256 x 128; kind 5: a 128-column half of 256 x 256 (two jobs) -- head layers of the reference's default
+// head [128, 256] -> 256 classes; kind 4 (256 x 256 in one 1024-thread workgroup) is kept for A/B runs only
 int wn_wgrad_pair_kind(int K, int N) {
   if (K == 128 && N == 256) return 1;
   if (K == 128 && N == 128) return 2;
+  if (K == 256 && N == 128) return 3;
+  if (K == 256 && N == 256) return 5;      // as two 256 x 128 column halves (kind 4, one 1024-thread workgroup, ran at 0.3 TB/s)
   return 0;
 }
 
@@ -186,6 +191,10 @@ int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws
   switch (kind) {
     case 1: hipLaunchKernelGGL((wn_wgrad_pair_kernel<128, 256, 4, 8>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
     case 2: hipLaunchKernelGGL((wn_wgrad_pair_kernel<128, 128, 4, 4>), grid, dim3(256), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
+    case 3: hipLaunchKernelGGL((wn_wgrad_pair_kernel<256, 128, 8, 4>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
+    case 4: hipLaunchKernelGGL((wn_wgrad_pair_kernel<256, 256, 8, 8>), grid, dim3(1024), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
+    // a 128-column half of a 256 x 256 product: G rows and dW rows keep their pitch of 256
+    case 5: hipLaunchKernelGGL((wn_wgrad_pair_kernel<256, 256, 8, 4, 256>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
     default: wn_set_error("wgrad_pairs: unknown kind %d", kind); return WN_E_UNSUPPORTED;
   }
   WN_HIP_CHECK(hipGetLastError());

@@ -37,6 +37,18 @@ def preprocess_waveform(x: torch.Tensor, recording_length: int, apply_mulaw: boo
   return frames[ok]
 
 
+def preprocess_with_condition(x: torch.Tensor, label: int, n_classes: int, recording_length: int, apply_mulaw: bool):
+  """The ``condition=True`` branch of preprocess_dataset (src/utils.py:42-50,57-63): every frame of an utterance
+  carries the utterance's one-hot class (the reference uses one_hot(gender, 2)); the validity filter looks at the
+  frame only.  Returns (frames (n, L+1, 1), cond (n, n_classes))."""
+  frames = preprocess_waveform(x, recording_length, apply_mulaw)
+  if not 0 <= int(label) < n_classes:
+    raise ValueError('label outside [0, n_classes)')
+  cond = torch.zeros(frames.shape[0], n_classes, dtype=torch.float32, device=frames.device)
+  cond[:, int(label)] = 1.0
+  return frames, cond
+
+
 def synthetic_waveforms(n: int, length: int, seed: int = 1234, device=None) -> torch.Tensor:
   """Benchmark input of SURVEY.md section 8d: two-tone + noise at 16 kHz, clipped, mu-law companded."""
   g = torch.Generator().manual_seed(seed)

@@ -317,12 +317,17 @@ class WaveNet(torch.nn.Module):
   # ------------------------------------------------------------------ call
   def call(self, inputs, training=False):
     """src/model.py:213-239: probabilities (categorical) or linear mixture parameters."""
-    if training and self.dropout > 0:
-      # dropout is applied inside train_step / loss_and_grads; a stand-alone stochastic forward is not exposed
-      raise NotImplementedError('call(training=True) with dropout > 0: use train_step / loss_and_grads')
     x, cond = self._split_inputs(inputs)
     B, T = x.shape[0], x.shape[1]
     L = _lib.lib()
+    if training and self.dropout > 0:
+      # the Dropout layers are active (src/layers.py:195-196): a fresh mask per call, as in a training step
+      ws = self._workspace('train', L.wn_plan_workspace_floats(self._plan, B, T, 1))
+      out = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device)
+      self._arm_dropout()
+      _lib.check(L.wn_forward_training(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                                       _lib.ptr(out), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+      return out
     ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
     out = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device)
     _lib.check(L.wn_forward(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
