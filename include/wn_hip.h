@@ -102,7 +102,9 @@ uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* t
  * block kernel (a pair per launch would time its own event packets too), else one pair per block;
  * wn_prof_read returns launches and the average per-launch time after a stream sync.
  * Not part of the reference surface. */
-int wn_debug_set(int key, int value);     /* tuning knobs for tools/ scripts */
+int wn_debug_set(int key, int value);     /* kernel-variant switches of the CALLING THREAD (list: csrc/wn_error.cpp);
+                                             key 1 = 1 selects the exact-fp32 MFMA kernels */
+int wn_debug_value(int key);              /* current value of a switch in the calling thread */
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
 int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
 /* test / diagnosis hook: float offset and length, inside the caller's TRAINING workspace for (B, T), of an
@@ -137,13 +139,13 @@ int wn_forward_training(wn_plan* p, const float* params, const float* x, const f
  * x_full (B,T+1,1): inputs = x[:, :-1], targets = prepare_target(x[:, 1:]).
  * loss = sum_{b,t} l / global_batch (+ l2 * sum W^2 / n_replicas).  grads receives
  * d(loss)/d(params) for THIS replica's rows (to be SUM-all-reduced by the caller).
- * loss_out: 2 device floats {loss, reg_loss}.  pred_out optional (B,T,C_out). */
+ * loss_out: 3 device floats {loss, reg_loss, range_flag}.  pred_out optional (B,T,C_out). */
 int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_full, const float* cond,
                      int32_t B, int32_t T, int32_t global_batch, int32_t n_replicas, float* grads,
                      float* loss_out, float* pred_out, float* workspace, int64_t ws_floats,
                      void* stream);
 
-/* ---- WaveNet.test_step loss, src/model.py:362-381 (forward + loss only) ---- */
+/* ---- WaveNet.test_step loss, src/model.py:362-381 (forward + loss only); loss_out: 3 device floats as above ---- */
 int wn_eval_loss(wn_plan* p, const float* params, const float* x_full, const float* cond,
                  int32_t B, int32_t T, int32_t global_batch, float* loss_out, float* pred_out,
                  float* workspace, int64_t ws_floats, void* stream);
@@ -154,6 +156,21 @@ int wn_eval_loss(wn_plan* p, const float* params, const float* x_full, const flo
 int wn_adam_step(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,
                  float lr, float beta1, float beta2, float eps, float clipnorm, float* scratch,
                  void* stream);
+/* the same update, skipped on the device when *skip_flag != 0 (the range flag of the step, after the data-parallel
+ * SUM: see "forward range guard" below); skip_flag may be NULL */
+int wn_adam_step_guarded(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,
+                         float lr, float beta1, float beta2, float eps, float clipnorm, float* scratch,
+                         const float* skip_flag, void* stream);
+
+/* ---- forward range guard of the split-precision mode ----
+ * The default kernels evaluate fp32 products from fp16 hi|lo operand splits; an activation beyond the fp16 range
+ * (65504) would turn into inf/NaN.  Every forward pass therefore keeps the running max-abs of the tensors that feed
+ * such kernels (residual stream, skip sum, head activations) in one workspace float: wn_train_fwd_bwd / wn_eval_loss
+ * write loss_out[2] = 1 when it reached wn_range_limit() (else 0; always 0 in exact-fp32 mode); wn_forward callers
+ * read the float at workspace[wn_plan_range_slot()].  A tripped pass must be repeated with the exact-fp32 kernels
+ * (wn_debug_set(1, 1)): the Python mirror does (WaveNet.train_step / call / test_step). */
+int64_t wn_plan_range_slot(const wn_plan* p, int32_t B, int32_t T, int32_t training);
+float wn_range_limit(void);
 
 /* ---- WaveNet.generate / _generation, src/model.py:241-307 (intended semantics) ----
  * window (B,RF,1) initial samples; out (B,length,1).  deterministic != 0: argmax / mode

@@ -668,6 +668,62 @@ def test_call_training_true_applies_dropout(math_mode):
   assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item()))
 
 
+@pytest.mark.parametrize('name', ['cat_small_fused', 'cat_r64', 'cat_r128'])
+def test_forward_range_guard_falls_back_to_exact_fp32(name):
+  """The split-precision kernels cast activations to fp16 hi|lo unscaled: a residual stream beyond 65504 would become
+  inf -> NaN.  The forward pass publishes the running max-abs of every tensor that feeds such a kernel; a tripped pass is
+  repeated with the exact-fp32 kernels (WaveNet.call / test_step / train_step) and the optimizer update of the tripped
+  attempt is skipped on the device.  Here the input conv's bias puts the residual stream at +-1e5."""
+  from wavenets_amd import Adam, _lib
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=6, **kw)
+  big = torch.where(torch.arange(params[1].numel()) % 2 == 0, 1.0e5, -1.0e5).to(params[1].dtype)
+  params[1] = params[1] + big                                     # causal/bias
+  model.set_weights([p.numpy() for p in params])
+  B, T = 2, 120
+  x, _ = _inputs(kw, B, T + 1, seed=3)
+  pd = [p.double() for p in params]
+  ref, inter = O.model_forward(x[:, :-1].double(), pd, ocfg, return_intermediates=True)
+  assert inter['h'][1].abs().max() > 9e4                           # the stream really is out of fp16 range
+  # the raw split-precision pass reports the overflow instead of hiding it
+  loss, _, _ = model.loss_and_grads(x.to(dev()))
+  assert loss[2].item() == 1.0
+  # guarded entry points: finite and equal to the oracle at fp32 resolution of a 1e5 stream (ulp 8e-3)
+  lg = model.logits(x[:, :-1].to(dev())).cpu().double()
+  assert torch.isfinite(lg).all() and (lg - inter['logits']).abs().max() < 5e-2
+  out = model(x[:, :-1].to(dev())).cpu().double()
+  assert (out - ref).abs().max() < 5e-3
+  model.compile(optimizer=None)
+  ev = model.test_step(x.to(dev()))
+  loss_ref, _, _, _ = O.loss_and_grads(x.double(), pd, ocfg)
+  assert abs(ev['loss'] - loss_ref.item()) < 2e-3 * abs(loss_ref.item())
+  # training: the tripped attempt must not touch the parameters or the moments; the repeated step is the real one
+  model.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0))
+  before = model.flat_params.data.clone()
+  logs = model.train_step(x.to(dev()))
+  assert model.optimizer.iterations == 1 and abs(logs['loss'] - loss_ref.item()) < 2e-3 * abs(loss_ref.item())
+  after = model.flat_params.data
+  assert torch.isfinite(after).all() and torch.isfinite(model.optimizer.m).all() and torch.isfinite(model.optimizer.v).all()
+  step = (after - before).abs()
+  assert step.max() <= 5e-4 * 1.001 + 1e-2 * 8e-3 and step.max() > 1e-4      # one Adam step of size lr (fp32 at 1e5: ulp 8e-3)
+  assert _lib.lib().wn_debug_value(1) == 0                       # the exact-fp32 switch is restored
+
+
+def test_forward_range_guard_quiet_for_tiny_activations():
+  """A residual stream of 1e-6 loses nothing that matters (absolute error of the fp16 lo part <= 3e-8): no fallback."""
+  kw = dict(MODEL_CASES['cat_r64'])
+  ocfg, params, model = make_pair(seed=6, **kw)
+  for i in (0, 1):
+    params[i] = params[i] * 1e-6                                   # causal kernel and bias
+  model.set_weights([p.numpy() for p in params])
+  x, _ = _inputs(kw, 2, 121, seed=3)
+  ref, inter = O.model_forward(x[:, :-1].double(), [p.double() for p in params], ocfg, return_intermediates=True)
+  assert inter['h'][0].abs().max() < 1e-5
+  loss, _, _ = model.loss_and_grads(x.to(dev()))
+  assert loss[2].item() == 0.0
+  assert (model.logits(x[:, :-1].to(dev())).cpu().double() - inter['logits']).abs().max() < ATOL_ACT
+
+
 def test_layer_dropout_training_mode():
   from wavenets_amd import WaveNetLayer
   layer = WaveNetLayer(channels=32, skip_channels=32, dilation_rate=2, dropout=0.5, device=dev())

@@ -69,6 +69,7 @@ _SIGS = {
     'wn_plan_dilation': (C.c_int32, [_P, C.c_int32]),
     'wn_plan_workspace_floats': (C.c_int64, [_P, C.c_int32, C.c_int32, C.c_int32]),
     'wn_debug_set': (C.c_int, [C.c_int, C.c_int]),
+    'wn_debug_value': (C.c_int, [C.c_int]),
     'wn_plan_set_dropout': (C.c_int, [_P, C.c_float, C.c_uint64, C.c_uint64]),
     'wn_dropout_key_for': (C.c_uint32, [C.c_uint64, C.c_int32, C.c_uint64]),
     'wn_prof_enable': (C.c_int, [_P, C.c_int32]),
@@ -86,6 +87,10 @@ _SIGS = {
     'wn_eval_loss': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
     'wn_adam_step': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, _P, _P]),
+    'wn_adam_step_guarded': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, _P, _P, _P]),
+    'wn_plan_range_slot': (C.c_int64, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    'wn_range_limit': (C.c_float, []),
     'wn_generate': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _P,
                               _P, C.c_int64, _P]),
     'wn_generate_workspace_floats': (C.c_int64, [_P, C.c_int32, C.c_int32]),

@@ -124,5 +124,15 @@ __device__ __forceinline__ void wn_absmax_publish(float* slot, float v) {
     atomicMax(reinterpret_cast<int*>(slot), __float_as_int(v));
 }
 
+// forward range guard: like wn_absmax_publish, but values at or beyond the float range (inf, NaN mapped to 3e38 by
+// the caller) are recorded too -- the guard has to see them
+__device__ __forceinline__ void wn_absmax_publish_any(float* slot, float v) {
+  if (v > 0.f && v > *reinterpret_cast<volatile float*>(slot))
+    atomicMax(reinterpret_cast<int*>(slot), __float_as_int(v));
+}
+
+// forward activations at or beyond this magnitude trip the range guard of the split-precision mode (fp16 max 65504)
+#define WN_RANGE_LIMIT 30000.0f
+
 void wn_set_error(const char* fmt, ...);
 int wn_debug_get(int key);   // tuning knobs (wn_error.cpp): 0 = layer-forward kernel variant

@@ -693,7 +693,8 @@ int wn_launch_sumsq(const float* g, const WnTensorDesc* d_table, int n, float* n
 
 __global__ void wn_adam_kernel(float* p, const float* g, float* m, float* v, const WnTensorDesc* table,
                                const float* norms2, float clipnorm, float alpha, float beta1,
-                               float beta2, float eps) {
+                               float beta2, float eps, const float* skip_flag) {
+  if (skip_flag && *skip_flag != 0.f) return;     // range guard tripped: the step is redone in exact fp32 (uniform)
   const WnTensorDesc d = table[blockIdx.y];
   float scale = 1.0f;
   if (clipnorm > 0.f) {
@@ -713,10 +714,10 @@ __global__ void wn_adam_kernel(float* p, const float* g, float* m, float* v, con
 }
 int wn_launch_adam(float* p, const float* g, float* m, float* v, const WnTensorDesc* d_table, int n,
                    const float* norms2, float clipnorm, float alpha, float beta1, float beta2,
-                   float eps, hipStream_t s) {
+                   float eps, const float* skip_flag, hipStream_t s) {
   if (n <= 0) return WN_OK;
   hipLaunchKernelGGL(wn_adam_kernel, dim3(32, n), dim3(256), 0, s, p, g, m, v, d_table, norms2,
-                     clipnorm, alpha, beta1, beta2, eps);
+                     clipnorm, alpha, beta1, beta2, eps, skip_flag);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
@@ -911,9 +912,10 @@ int wn_launch_cond_wgrad(const float* m, const float* dcb, int B, int Cc, int N,
 // Arithmetic = the k-ordered fma chain from zero, then + bias: what the fp32 MFMA product it replaces
 // computed and what the generation chain kernel (wn_gen.hip) reproduces, so all three agree bit for bit.
 __global__ __launch_bounds__(256) void wn_inconv_fwd_kernel(const float* x, const float* w, const float* bias, int B, int T,
-                                                            int R, int KS, float* y) {
+                                                            int R, int KS, float* y, float* absmax_out) {
   const int q = R / 4;                                   // float4 groups per row
   const int64_t total = (int64_t)B * T * q;
+  float wmax = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % q) * 4;
     const int64_t row = i / q;
@@ -926,15 +928,32 @@ __global__ __launch_bounds__(256) void wn_inconv_fwd_kernel(const float* x, cons
       a0 = fmaf(wv.x, xv, a0); a1 = fmaf(wv.y, xv, a1); a2 = fmaf(wv.z, xv, a2); a3 = fmaf(wv.w, xv, a3);
     }
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
-    *reinterpret_cast<f32x4*>(y + row * R + c) = f32x4{a0 + bv.x, a1 + bv.y, a2 + bv.z, a3 + bv.w};
+    const f32x4 o = f32x4{a0 + bv.x, a1 + bv.y, a2 + bv.z, a3 + bv.w};
+    *reinterpret_cast<f32x4*>(y + row * R + c) = o;
+    wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+  }
+  if (absmax_out) {                                      // forward range guard: running max-abs of the first block input
+    if (!(wmax < 3.0e38f)) wmax = 3.0e38f;               // inf / NaN count as "beyond any limit"
+    wmax = wn_wave_max(wmax);
+    if ((threadIdx.x & 63) == 0) wn_absmax_publish_any(absmax_out, wmax);
   }
 }
 int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int B, int T, int R, int KS, float* y,
-                         hipStream_t s) {
+                         float* absmax_out, hipStream_t s) {
   const int64_t total = (int64_t)B * T * (R / 4);
   if (total <= 0) return WN_OK;
   hipLaunchKernelGGL(wn_inconv_fwd_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, x, w, bias,
-                     B, T, R, KS, y);
+                     B, T, R, KS, y, absmax_out);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+__global__ void wn_guard_flag_kernel(const float* absmax, float limit, int enabled, float* out) {
+  const float m = absmax ? *absmax : 0.f;
+  out[0] = (enabled && !(m < limit)) ? 1.0f : 0.0f;
+}
+int wn_launch_guard_flag(const float* absmax, float limit, int enabled, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(wn_guard_flag_kernel, dim3(1), dim3(1), 0, s, absmax, limit, enabled, out);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

@@ -32,8 +32,11 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   15  = 1: last block's backward without the (zero) output gradient: one-segment product on the fp32 kernel
 //   19  = 1: head layers' weight gradients on the generic job table (no staged pair jobs)
 //   20  = 1: input conv's weight gradients on the generic job table (no dedicated reduction kernel)
-static int g_wn_debug[32] = {0};
+// thread-local: a caller that switches kernel variants (the range guard's exact-fp32 retry, tools/ A/B runs, tests)
+// affects the launches of its own thread only
+static thread_local int g_wn_debug[32] = {0};
 int wn_debug_get(int key) { return (key >= 0 && key < 32) ? g_wn_debug[key] : 0; }
+extern "C" int wn_debug_value(int key) { return wn_debug_get(key); }
 extern "C" int wn_debug_set(int key, int value) {
   if (key < 0 || key >= 32) return -1;
   g_wn_debug[key] = value;

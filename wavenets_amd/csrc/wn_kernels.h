@@ -142,6 +142,7 @@ struct WnLayerFwdArgs {
   const float* res;      // residual source [B*T][R] when it is not the conv input (depth > 1), or null
   const float* xt[3];    // queued generation: tap j reads rows of xt[j] (no time shift) instead of x; or null
   int32_t B, T, R, D, KS, dilation, residual;
+  float* absmax_out;     // split-precision kernel: running max-abs of x_out (forward range guard), or null
 };
 int wn_layer_fwd_supported(int R, int D, int KS);
 // fp16 hi/lo split (3-product) variant with LDS-resident weights; frag_d / frag_r are kind-1 images
@@ -215,7 +216,9 @@ int wn_inconv_wgrad_supported(int R, int KS);
 int wn_launch_inconv_wgrad(const float* x, const float* g, int B, int T, int R, int KS, int splits_per_b, float* slab,
                            int64_t P, int64_t w_off, int64_t b_off, hipStream_t s);
 int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int B, int T, int R, int KS, float* y,
-                         hipStream_t s);
+                         float* absmax_out, hipStream_t s);
+// out[0] = 1 when the split-precision kernels were fed a forward activation at or beyond `limit` (or a non-finite one)
+int wn_launch_guard_flag(const float* absmax, float limit, int enabled, float* out, hipStream_t s);
 int wn_launch_gen_tail_cat_det(const float* logits, int rows, int C, int bits, float* out, int length, int step,
                                float* xin_slot, hipStream_t s);
 int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s);
@@ -253,4 +256,4 @@ int wn_launch_axpy_table(float* y, const float* x, const WnTensorDesc* d_table, 
                          hipStream_t s);
 int wn_launch_adam(float* p, const float* g, float* m, float* v, const WnTensorDesc* d_table, int n,
                    const float* norms2, float clipnorm, float alpha, float beta1, float beta2,
-                   float eps, hipStream_t s);
+                   float eps, const float* skip_flag, hipStream_t s);

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
 
   const int tiles_per_b = (a.T + 31) >> 5;
   const int64_t ntiles = (int64_t)a.B * tiles_per_b;
+  float wmax = 0.f;                                      // forward range guard: max |x_out| of this wave's tiles
   for (int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * G::WAVES) {
     const int b = (int)(tile / tiles_per_b);
     const int t0 = (int)(tile % tiles_per_b) * 32;
@@ -247,8 +248,20 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
             o[j][4 * rq + 0] += xr.x; o[j][4 * rq + 1] += xr.y; o[j][4 * rq + 2] += xr.z; o[j][4 * rq + 3] += xr.w;
           }
       }
+      if (tin) {
+#pragma unroll
+        for (int j = 0; j < R32; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) wmax = fmaxf(wmax, fabsf(o[j][r]));
+      }
       wn_store_tile<R32, PITCH>(o, stage, a.x_out + row0 * R, R, rows_valid, lane);
     }
+  }
+  if (a.absmax_out) {
+    if (!(wmax < 3.0e38f)) wmax = 3.0e38f;               // inf / NaN: beyond any limit
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+    if (lane == 0) wn_absmax_publish_any(a.absmax_out, wmax);
   }
 }
 

@@ -260,6 +260,7 @@ struct WsLayout {
   std::vector<int64_t> XD;              // dropout: dropped copy of every block input (training)
   int64_t gxd;                          // dropout: scratch for d loss / d (dropped input)
   int64_t absmax; int n_absmax;         // running max-abs scalars: GF[i] | g_skipsum | GU[b] | GH[b]
+  int64_t fwd_absmax;                   // forward range guard: running max-abs of H[b], skip sum, head activations
   int64_t sum_scratch;
   std::vector<int64_t> M;               // mapping activations [B][w]
   int64_t cb;                           // [N][B][2D]
@@ -336,6 +337,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
   L.GZS = 0;
   L.n_absmax = (int)p->finals.size() + 1 + p->N + (p->N + 1);
   L.absmax = cv.take(L.n_absmax);
+  L.fwd_absmax = cv.take(1);
   // conditioning
   if (p->c.cond_inputs > 0) {
     for (size_t j = 0; j < p->mapping.size(); ++j) L.M.push_back(cv.take((int64_t)B * p->mapping[j].cout));
@@ -563,6 +565,7 @@ struct BlockBufs {
   const float* xt[3];       // queued generation: per-tap input rows (no time shift), or null
   const float* res;         // residual source when it is not x (dropout: x is the dropped copy), or null
   bool pre_done;            // queued generation: the non-gated convs already ran, xt[] are the gated conv's taps
+  float* fwd_absmax;        // forward range guard slot (running max-abs of x_out), or null
 };
 
 int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
@@ -593,6 +596,7 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     Gemm r(k.B, k.T, k.R, ceil32(k.R));
     r.seg(f.Z, f.ldz, k.D, 0, k.Fr).bias(k.br).w16(k.F16r);
     if (k.residual) r.addc(f.res ? f.res : f.x, k.Cin);
+    if (f.fwd_absmax) r.absmax(nullptr, nullptr, f.fwd_absmax);
     return r.run(f.x_out, k.R, s);
   }
   if (k.fused && k.Cc == 0 && hc == k.R) {
@@ -606,6 +610,7 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     a.res = f.res ? f.res : ((k.depth > 1) ? f.x : nullptr);
     a.xt[0] = f.xt[0]; a.xt[1] = f.xt[1]; a.xt[2] = f.xt[2];
     a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
+    a.absmax_out = f.fwd_absmax;
     return use16 ? wn_launch_layer_fwd_f16(a, s) : wn_launch_layer_fwd(a, s);
   }
   // composed path: u -> gate -> 1x1
@@ -1252,12 +1257,18 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     }
     }
   }
+  // Forward range guard.  The split-precision kernels cast fp32 activations to fp16 hi|lo unscaled: beyond 65504 the
+  // hi part is inf.  Every kernel that produces an input of such a kernel -- the residual stream H[b], the skip sum,
+  // the head activations (z is bounded by 1) -- publishes its running max-abs here; the callers turn it into a flag
+  // (WN_RANGE_LIMIT) and redo the pass with the exact-fp32 kernels when it tripped.
+  float* const fam = ws + L.fwd_absmax;
+  WN_HIP_CHECK(hipMemsetAsync(fam, 0, sizeof(float), s));
   // input causal conv, src/model.py:84-88,228 : KS taps with C_in = 1
   {
     if (p->R % 4 == 0 && wn_debug_get(1) != 1) {
       // elementwise kernel, same fma chain as the matrix product below computes for a K = 1 operand
       rc = wn_launch_inconv_fwd(x, params + p->tensors[p->causal.kernel_t].off, params + p->tensors[p->causal.bias_t].off, B, T,
-                                p->R, p->KS, ws + L.H[0], s);
+                                p->R, p->KS, ws + L.H[0], fam, s);
     } else {
       Gemm g(B, T, p->R, ceil32(p->R));
       for (int t = 0; t < p->KS; ++t)
@@ -1302,6 +1313,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;      // block-major [N][rows][Dp]
     f.O = nullptr;
     f.x_out = ws + L.H[ho];
+    f.fwd_absmax = rings ? nullptr : fam;
     const bool prof = p->prof_on && p->prof_used + 2 <= (int)p->prof_ev.size();
     const bool ev0 = prof && (!prof_chain || b == 0), ev1 = prof && (!prof_chain || b == p->N - 1);
     if (ev0) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
@@ -1328,7 +1340,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   if (p->c.use_skip) {
     rc = Gemm(B, T, p->Sh, ceil32(p->Sh)).seg_planes(ws + L.Z, p->Dp, rows * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
              .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
-             .bias(ws + L.bias_sum).run(ws + L.skipsum, p->Sh, s);
+             .bias(ws + L.bias_sum).absmax(nullptr, nullptr, fam).run(ws + L.skipsum, p->Sh, s);
     if (rc) return rc;
     hin = ws + L.skipsum;
   } else {
@@ -1343,7 +1355,8 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     float* dst = last ? ws + L.logits : ws + L.HA[i];
     rc = Gemm(B, T, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
              .w16(c.frag16 >= 0 ? fragbase + c.frag16 : nullptr)
-             .bias(params + p->tensors[c.bias_t].off).act(last ? WN_ACT_LINEAR : p->c.activation).run(dst, c.cout, s);
+             .bias(params + p->tensors[c.bias_t].off).act(last ? WN_ACT_LINEAR : p->c.activation)
+             .absmax(nullptr, nullptr, last ? nullptr : fam).run(dst, c.cout, s);
     if (rc) return rc;
     hin = dst; hc = c.cout;
   }
@@ -1601,6 +1614,8 @@ extern "C" int wn_eval_loss(wn_plan* p, const float* params, const float* x_full
   int rc = forward_core(p, params, inputs, true, cond, B, T, false, workspace, L, s);
   if (rc) return rc;
   rc = loss_stage(p, B, T, global_batch > 0 ? global_batch : B, false, workspace, L, loss_out, nullptr, s);
+  if (rc) return rc;
+  rc = wn_launch_guard_flag(workspace + L.fwd_absmax, WN_RANGE_LIMIT, wn_debug_get(1) != 1, loss_out + 2, s);
   if (rc) return rc;
   if (pred_out) {
     if (p->c.head == WN_HEAD_CATEGORICAL) return wn_launch_softmax(workspace + L.logits, pred_out, rows, p->Cout, s);
@@ -1970,6 +1985,8 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
     if (rc) return rc;
   }
+  rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT, wn_debug_get(1) != 1, loss_out + 2, s);
+  if (rc) return rc;
   if (p->phase_on) {
     if (!defer) (void)hipEventRecord(p->phase_ev[3], s);             // per-call weight gradients: no separate phase
     (void)hipEventRecord(p->phase_ev[4], s);
@@ -1977,9 +1994,9 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   return WN_OK;
 }
 
-extern "C" int wn_adam_step(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,
-                            float lr, float beta1, float beta2, float eps, float clipnorm, float* scratch,
-                            void* stream) {
+extern "C" int wn_adam_step_guarded(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,
+                                    float lr, float beta1, float beta2, float eps, float clipnorm, float* scratch,
+                                    const float* skip_flag, void* stream) {
   if (!p || !params || !grads || !m || !v || !scratch || step < 1) { wn_set_error("adam_step: bad arguments"); return WN_E_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   int rc = ensure_device_tables(p);
@@ -1990,8 +2007,21 @@ extern "C" int wn_adam_step(wn_plan* p, float* params, const float* grads, float
     if (rc) return rc;
   }
   const double alpha = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-  return wn_launch_adam(params, grads, m, v, p->d_tdesc, n, scratch, clipnorm, (float)alpha, beta1, beta2, eps, s);
+  return wn_launch_adam(params, grads, m, v, p->d_tdesc, n, scratch, clipnorm, (float)alpha, beta1, beta2, eps, skip_flag, s);
 }
+
+extern "C" int wn_adam_step(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,
+                            float lr, float beta1, float beta2, float eps, float clipnorm, float* scratch,
+                            void* stream) {
+  return wn_adam_step_guarded(p, params, grads, m, v, step, lr, beta1, beta2, eps, clipnorm, scratch, nullptr, stream);
+}
+
+// forward range guard of an inference call: reads nothing back, only tells where the slot is
+extern "C" int64_t wn_plan_range_slot(const wn_plan* p, int32_t B, int32_t T, int32_t training) {
+  if (!p || B < 1 || T < 1) return -1;
+  return make_layout(p, B, T, training != 0).fwd_absmax;
+}
+extern "C" float wn_range_limit(void) { return WN_RANGE_LIMIT; }
 
 // ==========================================================================================
 // generation: WaveNet.generate / _generation, src/model.py:241-307 (intended semantics:

@@ -221,8 +221,8 @@ class WaveNet(torch.nn.Module):
         cnt = int(np.prod(shp))
         flat[o:o + cnt] = (torch.rand(cnt, generator=g) * 2 - 1) * lim
     self.flat_params = torch.nn.Parameter(flat.to(self._device), requires_grad=False)
-    # gradient bucket = [flat gradient | loss, reg_loss]: the data-parallel exchange is ONE all-reduce
-    self._grad_bucket = torch.zeros(self.flat_params.numel() + 2, dtype=torch.float32, device=self._device)
+    # gradient bucket = [flat gradient | loss, reg_loss, range_flag]: the data-parallel exchange is ONE all-reduce
+    self._grad_bucket = torch.zeros(self.flat_params.numel() + 3, dtype=torch.float32, device=self._device)
     self.flat_grads = self._grad_bucket[:self.flat_params.numel()]
     self.built = True
     if self.optimizer is not None:
@@ -316,22 +316,30 @@ class WaveNet(torch.nn.Module):
 
   # ------------------------------------------------------------------ call
   def call(self, inputs, training=False):
-    """src/model.py:213-239: probabilities (categorical) or linear mixture parameters."""
+    """src/model.py:213-239: probabilities (categorical) or linear mixture parameters.  (Reads the pass's range-guard
+    float back -- one host sync -- and repeats the pass with the exact-fp32 kernels when an activation left the range
+    of the split-precision ones.)"""
     x, cond = self._split_inputs(inputs)
+    return self._forward_guarded(x, cond, want_probs=True, training=bool(training and self.dropout > 0))
+
+  def _forward_guarded(self, x, cond, want_probs, training):
     B, T = x.shape[0], x.shape[1]
     L = _lib.lib()
-    if training and self.dropout > 0:
-      # the Dropout layers are active (src/layers.py:195-196): a fresh mask per call, as in a training step
-      ws = self._workspace('train', L.wn_plan_workspace_floats(self._plan, B, T, 1))
-      out = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device)
-      self._arm_dropout()
-      _lib.check(L.wn_forward_training(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
-                                       _lib.ptr(out), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
-      return out
-    ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
+    ws = self._workspace('train' if training else 'fwd', L.wn_plan_workspace_floats(self._plan, B, T, int(training)))
     out = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device)
-    _lib.check(L.wn_forward(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
-                            _lib.ptr(out), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    fn = L.wn_forward_training if training else L.wn_forward
+    if training:
+      # the Dropout layers are active (src/layers.py:195-196): a fresh mask per call, as in a training step
+      self._arm_dropout()
+
+    def run():
+      _lib.check(fn(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                    _lib.ptr(out) if want_probs else None, None if want_probs else _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                    _lib.stream_ptr()))
+    run()
+    if L.wn_debug_value(1) != 1 and self._range_tripped(ws, B, T, training):
+      with self.exact_fp32():
+        run()
     return out
 
   def forward(self, inputs, training=False):
@@ -340,13 +348,7 @@ class WaveNet(torch.nn.Module):
   def logits(self, inputs):
     """Pre-softmax head output (parity checks)."""
     x, cond = self._split_inputs(inputs)
-    B, T = x.shape[0], x.shape[1]
-    L = _lib.lib()
-    ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
-    out = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device)
-    _lib.check(L.wn_forward(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
-                            None, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
-    return out
+    return self._forward_guarded(x, cond, want_probs=False, training=False)
 
   # ------------------------------------------------------------------ training
   @staticmethod
@@ -379,6 +381,28 @@ class WaveNet(torch.nn.Module):
       values = values / world
     return values
 
+  def exact_fp32(self):
+    """Context manager: the calling thread's launches use the exact-fp32 MFMA kernels (no fp16 hi|lo operand split)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def _cm():
+      L = _lib.lib()
+      prev = L.wn_debug_value(1)
+      L.wn_debug_set(1, 1)
+      try:
+        yield
+      finally:
+        L.wn_debug_set(1, prev)
+    return _cm()
+
+  def _range_tripped(self, ws, B, T, training):
+    """Reads the forward range-guard slot of the pass just enqueued on ``ws`` (one host sync)."""
+    L = _lib.lib()
+    slot = L.wn_plan_range_slot(self._plan, B, T, int(training))
+    m = float(ws[slot])
+    return not (m < L.wn_range_limit())
+
   def set_drop_step(self, n: int):
     """Training calls already made (resume): the next dropout mask is that of call n + 1."""
     self._drop_step = int(n)
@@ -396,7 +420,9 @@ class WaveNet(torch.nn.Module):
     """Forward + loss + backward of this replica's rows (src/model.py:319-335).
 
     Fills ``self.flat_grads`` with d(sum_local l / B_global)/d(theta); returns
-    (loss tensor[2] = {loss, reg_loss}, pred or None, y_true).  ``want_sample``: the step also draws
+    (loss tensor[3] = {loss, reg_loss, range_flag}, pred or None, y_true).  range_flag = 1: a forward activation left
+    the range of the split-precision kernels and the results are not valid (train_step then repeats the step with the
+    exact-fp32 kernels; a direct caller checks loss[2] and does the same through ``exact_fp32()``).  ``want_sample``: the step also draws
     ``sample_waveform(pred)`` (src/model.py:338) from the logits inside the library -- same draw, no (B,T,C)
     probability tensor -- and returns it in place of pred; when the library cannot (deterministic / more than
     1024 classes) pred is returned and the caller samples from it."""
@@ -413,7 +439,7 @@ class WaveNet(torch.nn.Module):
     ws = self._workspace('train', L.wn_plan_workspace_floats(self._plan, B, T, 1))
     # train_step keeps {loss, reg_loss} in the gradient bucket's tail (one all-reduce); other callers get their own tensor
     loss = self._grad_bucket[self.flat_params.numel():] if _loss_in_bucket else \
-        torch.empty(2, dtype=torch.float32, device=self._device)
+        torch.empty(3, dtype=torch.float32, device=self._device)
     sample = None
     if want_sample and self._fused_step_sample:
       sample = torch.empty(B, T, 1, dtype=torch.float32, device=self._device)
@@ -436,21 +462,21 @@ class WaveNet(torch.nn.Module):
     return loss, pred, x[:, 1:, :]
 
   def train_step(self, data):
-    """src/model.py:309-348.  Data-parallel: the flat gradient (and the two loss scalars) are
-    SUM-all-reduced over RCCL before the (replicated, deterministic) optimizer step."""
+    """src/model.py:309-348.  Data-parallel: the flat gradient (and the loss scalars) are
+    SUM-all-reduced over RCCL before the (replicated, deterministic) optimizer step.
+
+    Range guard: the split-precision kernels need |activation| < 65504.  The step's range flag rides in the bucket's
+    tail through the all-reduce, the optimizer kernel skips the update on every replica when it is set, and the step is
+    then repeated here with the exact-fp32 kernels (same dropout mask, same optimizer iteration)."""
     if self.optimizer is None:
       raise RuntimeError('compile(optimizer=...) first')
-    want_metric = len(self._metrics_from_compilation) > 0
-    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True)
-    from . import dp
-    dp.allreduce_bucket(self._grad_bucket)              # gradients + {loss, reg_loss}; no-op for a single replica
-    self.optimizer.apply_gradients(self)
-    # metrics that can reduce on the device do so behind the optimizer; ONE read brings back loss, reg_loss and them
-    pending = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
-               if hasattr(m, 'update_state_device')]
-    mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
-    lv = (torch.cat([loss, mv]) if pending else loss).tolist()
-    for (m, _), v in zip(pending, lv[2:]):
+    lv, pending, y_true, sample = self._train_step_once(data)
+    if lv[2] > 0:                                    # tripped on some replica -> on all of them after the SUM
+      self.optimizer.iterations -= 1
+      self._drop_step -= 1 if self.dropout > 0 else 0
+      with self.exact_fp32():
+        lv, pending, y_true, sample = self._train_step_once(data)
+    for (m, _), v in zip(pending, lv[3:]):
       m.commit(v)
     for metric in self.metrics:
       if metric.name == 'loss':
@@ -461,30 +487,48 @@ class WaveNet(torch.nn.Module):
         metric.update_state(y_true, sample)
     return {m.name: m.result() for m in self.metrics}
 
+  def _train_step_once(self, data):
+    want_metric = len(self._metrics_from_compilation) > 0
+    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True)
+    from . import dp
+    dp.allreduce_bucket(self._grad_bucket)              # gradients + {loss, reg_loss, range_flag}; no-op for a single replica
+    self.optimizer.apply_gradients(self, skip_flag=loss[2:3])
+    # metrics that can reduce on the device do so behind the optimizer; ONE read brings back loss, reg_loss, flag and them
+    pending = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
+               if hasattr(m, 'update_state_device')]
+    mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
+    lv = (torch.cat([loss, mv]) if pending else loss).tolist()
+    return lv, pending, y_true, sample
+
   def test_step(self, data):
-    """src/model.py:362-391."""
+    """src/model.py:362-391 (range guard as in train_step: a tripped pass is repeated with the exact-fp32 kernels)."""
     x, cond = self._split_inputs(data)
     B, T = x.shape[0], x.shape[1] - 1
     world = self._world()
     L = _lib.lib()
     ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
-    loss = torch.empty(2, dtype=torch.float32, device=self._device)
+    loss = torch.empty(3, dtype=torch.float32, device=self._device)
     want_metric = len(self._metrics_from_compilation) > 0
     pred = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device) if want_metric else None
-    _lib.check(L.wn_eval_loss(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
-                              B * world, _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(),
-                              _lib.stream_ptr()))
-    if world > 1:
-      import torch.distributed as dist
-      dist.all_reduce(loss[:1], op=dist.ReduceOp.SUM)
-    if want_metric:
-      sample = self.sample_waveform(pred)
-    # as in train_step: device-side metric reductions first, then ONE device-to-host read
-    pending = [(m, m.update_state_device(x[:, 1:, :], sample)) for m in self._metrics_from_compilation
-               if hasattr(m, 'update_state_device')]
-    mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
-    lv = (torch.cat([loss, mv]) if pending else loss).tolist()
-    for (m, _), v in zip(pending, lv[2:]):
+
+    def once():
+      _lib.check(L.wn_eval_loss(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
+                                B * world, _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(),
+                                _lib.stream_ptr()))
+      if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(loss, op=dist.ReduceOp.SUM)      # loss sums over the replicas; reg_loss unused; flag: any replica
+      sample = self.sample_waveform(pred) if want_metric else None
+      # as in train_step: device-side metric reductions first, then ONE device-to-host read
+      pending = [(m, m.update_state_device(x[:, 1:, :], sample)) for m in self._metrics_from_compilation
+                 if hasattr(m, 'update_state_device')]
+      mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
+      return (torch.cat([loss, mv]) if pending else loss).tolist(), pending, sample
+    lv, pending, sample = once()
+    if lv[2] > 0:
+      with self.exact_fp32():
+        lv, pending, sample = once()
+    for (m, _), v in zip(pending, lv[3:]):
       m.commit(v)
     for metric in self.metrics:
       if metric.name == 'loss':

@@ -28,11 +28,14 @@ class Adam:
       self._scratch = torch.zeros(len(model.variable_names) + 8, dtype=torch.float32,
                                   device=model.flat_params.device)
 
-  def apply_gradients(self, model):
-    """One update of model.flat_params from model.flat_grads (src/model.py:336)."""
+  def apply_gradients(self, model, skip_flag=None):
+    """One update of model.flat_params from model.flat_grads (src/model.py:336).  ``skip_flag``: a device float;
+    when it is non-zero the kernel leaves parameters and moments untouched (the range guard of the split-precision
+    mode tripped and the caller repeats the step with the exact-fp32 kernels, see WaveNet.train_step)."""
     self.build(model)
     self.iterations += 1
-    _lib.check(_lib.lib().wn_adam_step(
+    _lib.check(_lib.lib().wn_adam_step_guarded(
         model._plan, _lib.ptr(model.flat_params), _lib.ptr(model.flat_grads), _lib.ptr(self.m),
         _lib.ptr(self.v), self.iterations, self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
-        float(self.clipnorm) if self.clipnorm else 0.0, _lib.ptr(self._scratch), _lib.stream_ptr()))
+        float(self.clipnorm) if self.clipnorm else 0.0, _lib.ptr(self._scratch), _lib.ptr(skip_flag),
+        _lib.stream_ptr()))
