@@ -119,7 +119,13 @@ def test_30_block_activations_loss_and_all_gradients(name, math_mode):
   for b, h in enumerate(inter['h']):
     worst_act = max(worst_act, (ws(0, b, h.shape) - h).abs().max().item())
     assert worst_act < ATOL_ACT, (name, math_mode, f'H[{b}]', worst_act)
-  assert (ws(3, 0, inter['skip_sum'].shape) - inter['skip_sum']).abs().max().item() < ATOL_ACT
+  try:
+    assert (ws(3, 0, inter['skip_sum'].shape) - inter['skip_sum']).abs().max().item() < ATOL_ACT
+    folded = False
+  except ValueError:
+    # split-precision training passes fold the skip path into the head's first conv (a = sum_b (W_s(b) W_f0)^T z_b + b'):
+    # the skip sum is never formed; its consumer, the first head activation, is compared below
+    folded = True
   branch = []
   for i, a in enumerate(inter['head_pre']):
     ha = ws(4, i, a.shape)
@@ -128,8 +134,16 @@ def test_30_block_activations_loss_and_all_gradients(name, math_mode):
   # ---- loss, data gradients at the skip sum and at every block input, every parameter gradient ----
   loss_ref, grads_ref, g_skip_ref, g_h_ref, n_kink = _oracle_grads(name, branch)
   assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item())), (loss[0].item(), loss_ref.item())
-  e = (ws(7, 0, g_skip_ref.shape) - g_skip_ref).abs().max().item()
+  if folded:
+    # d loss / d skip sum = (d loss / d a) W_f0^T, a = pre-activation of the first head conv (kept in the workspace)
+    names = model.variable_names
+    w_f0 = params[names.index('final0/kernel')].double()[0]                       # (S, F0)
+    g_skip = ws(6, 0, inter['head_pre'][0].shape) @ w_f0.T
+  else:
+    g_skip = ws(7, 0, g_skip_ref.shape)
+  e = (g_skip - g_skip_ref).abs().max().item()
   assert e < 1e-4 * g_skip_ref.abs().max().item(), (name, math_mode, 'd loss / d skip sum', e)
+  assert folded == (math_mode == 'split')
   for b, r in enumerate(g_h_ref):
     e = (ws(9, b, r.shape) - r).abs().max().item()
     assert e < 1e-4 * r.abs().max().item(), (name, math_mode, f'd loss / d H[{b}]', e)

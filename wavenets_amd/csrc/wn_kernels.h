@@ -211,6 +211,15 @@ int wn_launch_cond_gather(const float* slab, int64_t P, int spb, int64_t bd_off0
                           float* dcb, hipStream_t s);
 int wn_launch_cond_wgrad(const float* m, const float* dcb, int B, int Cc, int N, int D2, float* grads, int64_t w_off0,
                          int64_t w_stride, int64_t b_off0, int64_t b_stride, hipStream_t s);
+// skip path folded into the head's first convolution (wn_elem.hip): V(b) = W_s(b) W_f0, b' = b_f0 + W_f0^T sum b_s;
+// and the weight gradients of conv_skip (all blocks) and of that convolution from M = Z^T dL/da
+int wn_launch_skip_fold(const float* params, int64_t ws_off0, int64_t ws_stride, int64_t wf0_off, int64_t bf0_off,
+                        const float* bsum, int N, int D, int S, int F0, float* V, float* bfold, float* wsall, hipStream_t s);
+// C[i][j] = sum_k A[i * sai + k * sak] * B[k * sbk + j * sbj] (small fp32 product, LDS-tiled)
+int wn_launch_sgemm_small(const float* A, int64_t sai, int64_t sak, const float* B, int64_t sbk, int64_t sbj, float* C, int ldc,
+                          int M, int N, int K, hipStream_t s);
+int wn_launch_skip_scatter(const float* Y, const float* colsum, int64_t ws_off0, int64_t ws_stride, int64_t bs_off0,
+                           int64_t bs_stride, int64_t bf0_off, int N, int D, int S, int F0, float* grads, hipStream_t s);
 // dW, db of the input causal conv into the batched weight-gradient slab (wn_elem.hip)
 int wn_inconv_wgrad_supported(int R, int KS);
 int wn_launch_inconv_wgrad(const float* x, const float* g, int B, int T, int R, int KS, int splits_per_b, float* slab,

@@ -48,6 +48,7 @@ struct BlockInfo {
   int64_t g16u = -1;    // fp16 split image [W_r | W_s] (backward: d z) or -1
   int64_t g16r = -1;    // fp16 split image [W_r] alone (used with the precomputed W_s g_skip slice) or -1
   int64_t f16gate = -1; // fp16 split image of the gated conv with row tiles ordered [f f g g] per 64 channels, or -1
+  int64_t g16uf = -1;   // fp16 split image [W_r | V(b)], V(b) = W_s(b) W_f0 (skip path folded into the first head conv), or -1
 };
 
 }  // namespace
@@ -68,6 +69,13 @@ struct wn_plan {
   int64_t frag16_skipF = -1;   // the same as an fp16 split image, or -1
   int64_t frag16_gzs = -1;     // fp16 split image A[N*D][S]: rows b*D.. = W_s of block b (backward of the folded skip sum)
   int64_t frag_floats = 0;
+  // skip path folded into the head's first convolution (training passes; see wn_skip_fold_kernel): F0 = its width,
+  // forward image A[F0][N*D] of V^T.  prep2 = pieces whose SOURCE is the workspace (the V matrix), not the parameters
+  int fold_F0 = 0;
+  int64_t frag16_foldF = -1;
+  std::vector<WnPrepDesc> prep2;
+  WnPrepDesc* d_prep2 = nullptr;
+  WnTensorDesc* d_cov_fold = nullptr;
   std::vector<WnPrepDesc> prep;
   std::vector<WnTensorDesc> tdesc, kdesc;
   // device copies (lazy)
@@ -95,6 +103,7 @@ struct wn_plan {
   int hpair_first[6] = {0, 0, 0, 0, 0, 0}, hpair_count[6] = {0, 0, 0, 0, 0, 0};
   bool jobs_headpairs = false;
   bool jobs_inconvk = false;    // input conv's dW / db from the dedicated reduction kernel, not from jobs
+  bool jobs_fold = false;       // tables built for the folded skip path (no conv_skip / first-head-conv entries)
   // side stream: the low-occupancy generic weight-gradient jobs overlap the per-block / skip kernels
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -219,6 +228,14 @@ int ensure_device_tables(wn_plan* p) {
     WN_HIP_CHECK(hipMalloc((void**)&p->d_kdesc, p->kdesc.size() * sizeof(WnTensorDesc)));
     WN_HIP_CHECK(hipMemcpy(p->d_kdesc, p->kdesc.data(), p->kdesc.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
   }
+  if (!p->prep2.empty()) {
+    WN_HIP_CHECK(hipMalloc((void**)&p->d_prep2, p->prep2.size() * sizeof(WnPrepDesc)));
+    WN_HIP_CHECK(hipMemcpy(p->d_prep2, p->prep2.data(), p->prep2.size() * sizeof(WnPrepDesc), hipMemcpyHostToDevice));
+    WnTensorDesc d;
+    d.off = 0; d.len = (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0;
+    WN_HIP_CHECK(hipMalloc((void**)&p->d_cov_fold, sizeof(WnTensorDesc)));
+    WN_HIP_CHECK(hipMemcpy(p->d_cov_fold, &d, sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+  }
   return WN_OK;
 }
 
@@ -256,6 +273,10 @@ struct WsLayout {
   // the input conv's (KS + 1) * R sums have a compact slab of their own too: [B * isplits][(KS + 1) * R] (its kernel
   // and bias are the first two tensors of the flat buffer), so that the 33 MB stream is spread over ~512 workgroups
   int64_t islab; int isplits;
+  // folded skip path: V [N*D][F0], b' [F0] (fixed offsets right behind the images), [W_s(all blocks); sum b_s]
+  // ([N*D + 1][S]), the slab [B*bsplits][N*D*F0 + F0] of M = Z^T dL/da with the column sums behind it, its reduced
+  // form [M; colsum] and Y = [M; colsum] W_f0^T ([N*D + 1][S])
+  int64_t vfold, bfold, wsall, mslab, mtot, ytmp;
   int64_t GZS;                          // [rows][N*D] precomputed W_s g_skip of every block, or 0
   std::vector<int64_t> XD;              // dropout: dropped copy of every block input (training)
   int64_t gxd;                          // dropout: scratch for d loss / d (dropped input)
@@ -292,12 +313,19 @@ int count_jobs(const wn_plan* p) {
   return n;
 }
 
+// Training passes fold the skip path into the head's first convolution when the plan has the images for it
+// (fold_F0 > 0: depth-1 blocks with skip convs feeding a head whose first conv is narrower than the skip width) and the
+// split-precision kernels run; knob 21 = 1 keeps the reference's two-step form (skip sum, then the head conv).
+bool fold_ok(const wn_plan* p) {
+  return p->fold_F0 > 0 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(21) != 1 && wn_debug_get(4) != 1;
+}
+
 // the head layers' weight gradients run as staged pair jobs when every final layer has a pair kind (widths 128 / 256)
 // in split-precision mode; knob 19 = 1 keeps them on the generic job table
 bool head_pairs_ok(const wn_plan* p) {
   if (p->finals.empty() || wn_debug_get(1) == 1 || wn_debug_get(3) == 1 || wn_debug_get(19) == 1) return false;
-  for (const ConvInfo& c : p->finals)
-    if (wn_wgrad_pair_kind(c.cin, c.cout) == 0) return false;
+  for (size_t i = fold_ok(p) ? 1 : 0; i < p->finals.size(); ++i)      // (folded: the first conv's gradients come from M)
+    if (wn_wgrad_pair_kind(p->finals[i].cin, p->finals[i].cout) == 0) return false;
   return true;
 }
 
@@ -307,6 +335,11 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
   const int64_t rows = (int64_t)B * T;
   L.frag = cv.take(p->frag_floats);
   L.bias_sum = cv.take(p->Hin);
+  // (fixed offsets: the prep2 table addresses V relative to the workspace base, whatever B and T are)
+  L.vfold = cv.take(p->fold_F0 > 0 ? (int64_t)(p->N * p->D + 1) * p->fold_F0 : 0);     // (+ the row W_f0^T sum b_s)
+  L.bfold = cv.take(p->fold_F0 > 0 ? p->fold_F0 : 0);
+  L.wsall = cv.take(p->fold_F0 > 0 ? (int64_t)(p->N * p->D + 1) * p->S : 0);
+  L.mslab = L.mtot = L.ytmp = 0;
   const int nH = training ? p->N + 1 : 2;
   const int hc = std::max(p->R, p->D);
   for (int i = 0; i < nH; ++i) L.H.push_back(cv.take(rows * hc));
@@ -372,6 +405,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
       if (b.has_skip) need = std::max(need, slab_need(B, T, p->D, p->S));
     }
     for (const ConvInfo& c : p->finals) need = std::max(need, slab_need(B, T, c.cin, c.cout));
+    if (p->fold_F0 > 0) need = std::max(need, slab_need(1, p->N * p->D + 1, p->S, p->fold_F0));
     for (const ConvInfo& c : p->mapping) need = std::max(need, slab_need(1, B, c.cin, c.cout));
     if (p->c.cond_inputs > 0) {
       need = std::max(need, slab_need(1, B, p->Cc, 2 * p->D));
@@ -395,6 +429,12 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
       if (wn_debug_get(10) > 0) sp = std::max(1, std::min(wn_debug_get(10), maxsp));   // knob 10: time splits per utterance
       L.bsplits = sp;
       L.bslab = cv.take((int64_t)B * sp * p->nparams);
+      if (p->fold_F0 > 0) {
+        const int64_t pm = (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0;
+        L.mslab = cv.take((int64_t)B * sp * pm);
+        L.mtot = cv.take(pm);
+        L.ytmp = cv.take((int64_t)(p->N * p->D + 1) * p->S);
+      }
       if (wn_inconv_wgrad_supported(p->R, p->KS) && p->tensors[p->causal.kernel_t].off == 0 &&
           p->tensors[p->causal.bias_t].off == (int64_t)p->KS * p->R) {
         L.isplits = std::max(1, std::min((512 + B - 1) / B, std::max(1, T / 64)));
@@ -488,6 +528,8 @@ struct Gemm {
     // knob 1 = 1 forces the exact-fp32 MFMA kernels
     if (w16_ && wn_debug_get(1) != 1 && wn_gemm_rows16_ok(a)) return wn_launch_gemm_rows16(a, w16_, am0_, am1_, amo_, s);
     if (a.epi == WN_EPI_GATE_FWD) { wn_set_error("gate-forward contraction needs the split-precision kernel (alignment / shape)"); return WN_E_UNSUPPORTED; }
+    for (int i = 0; i < a.nseg; ++i)
+      if (!a.seg[i].frag) { wn_set_error("contraction without an fp32 weight image needs the split-precision kernel"); return WN_E_UNSUPPORTED; }
     return wn_launch_gemm_rows(a, s);
   }
 };
@@ -551,6 +593,7 @@ struct BlockPtrs {
   const float* F16d; const float* F16r;   // fp16 split images of the gated conv / conv1, or null
   const float* G16u; const float* G16x;   // fp16 split images of the backward-data products, or null
   const float* G16r;                      // [W_r] alone
+  const float* G16uf;                     // [W_r | V(b)]: skip path folded into the first head conv (training), or null
   const float* F16g;                      // gated conv, row tiles [f f g g] per 64 channels (composed split-precision forward), or null
 };
 
@@ -658,6 +701,7 @@ struct BlockGrads {
   const float* am_gxout; const float* am_gskip;   // running max-abs of g_xout / g_skip (or null)
   float* am_gu; float* am_gx;                      // where to publish max-abs of g_u / g_x (or null)
   const float* gzs; int ld_gzs;                    // precomputed W_s g_skip slice of this block, or null
+  const float* g_fold; int fold_F0; const float* am_gfold;   // folded skip path: dL/da of the first head conv [rows][F0] replaces g_skip
   float drop_rate; uint32_t drop_key; float* g_xd;  // dropout on the block input: mask the conv-path gradient
 };
 
@@ -682,10 +726,12 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
   {
     Gemm gm(k.B, k.T, k.D, ceil32(k.D));
     const bool use_gzs = g.gzs && g_o && k.G16r && g.am_gu && g.am_gxout && k.Cc == 0;
-    if (g_o) gm.seg(g_o, k.R, k.R, 0, k.Br_);
-    if (use_gzs) gm.addc(g.gzs, g.ld_gzs).w16(k.G16r).absmax(g.am_gxout, nullptr, g.am_gu);
+    const bool use_fold = g.g_fold && g_o && k.G16uf && g.am_gu && g.am_gxout && g.am_gfold && k.Cc == 0;
+    if (g_o) gm.seg(g_o, k.R, k.R, 0, use_fold ? nullptr : k.Br_);
+    if (use_fold) gm.seg(g.g_fold, g.fold_F0, g.fold_F0, 0, nullptr).w16(k.G16uf).absmax(g.am_gxout, g.am_gfold, g.am_gu);
+    else if (use_gzs) gm.addc(g.gzs, g.ld_gzs).w16(k.G16r).absmax(g.am_gxout, nullptr, g.am_gu);
     else if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, k.Bs);
-    if (use_gzs) {
+    if (use_gzs || use_fold) {
       rc = gm.gate_bwd(f.AG, k.D, f.Z, f.ldz).run(g.g_u, 2 * k.D, s);
     } else if (gm.a.nseg == 0) {
       rc = wn_launch_fill(g.g_u, 0.f, rows * 2 * k.D, s);
@@ -965,6 +1011,20 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
       add_piece16(p, bi.g16r, p->D, p->tensors[bi.conv1.kernel_t].off, p->R, p->R, 0, 0);
     }
   }
+  // skip path folded into the head's first conv: needs skip convs feeding a head with >= 1 hidden layer narrower than S
+  if (p->LPB == 1 && p->c.use_skip && p->S > 0 && p->finals.size() >= 2 && p->finals[0].cout < p->S && m32(p->finals[0].cout) &&
+      m32(p->D) && p->D % 64 == 0 && m16(p->R) && m16(p->S) && p->Dp == p->D && p->frag16_skipF >= 0 &&
+      wn_wgrad_skip_supported(p->D, p->finals[0].cout, p->N * p->D) && p->finals[0].frag16B >= 0) {
+    const int F0 = p->finals[0].cout;
+    p->fold_F0 = F0;
+    // offsets of V inside the workspace (make_layout: images, bias_sum, V, ...) -- fixed for the plan
+    // (frag_floats is still growing here: the prep2 descriptors are finished at the end of this function)
+    p->frag16_foldF = new_image16(p, F0, p->N * p->D);
+    for (BlockInfo& bi : p->blocks) {
+      bi.g16uf = new_image16(p, p->D, p->R + F0);
+      add_piece16(p, bi.g16uf, p->D, p->tensors[bi.conv1.kernel_t].off, p->R, p->R, 0, 0);
+    }
+  }
   if (p->LPB == 1 && m32(p->R) && m16(2 * p->D)) {
     for (BlockInfo& bi : p->blocks) {
       // d x = sum_tap W_tap g_u[t + shift] : image of KS pieces A[R][2D], I = R
@@ -975,6 +1035,21 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
                     2 * p->D, 0, t * (2 * p->D / 16));
     }
   }
+  if (p->fold_F0 > 0) {
+    // pieces read from the workspace: V = [N*D][F0] at the fixed offset make_layout gives it
+    const int F0 = p->fold_F0;
+    const int64_t voff = make_layout(p, 1, 1, false).vfold;
+    auto piece2 = [&](int64_t img, int I, int64_t src_off, int KK, int ld, int transpose, int ks_off) {
+      WnPrepDesc d;
+      memset(&d, 0, sizeof(d));
+      d.src_off = src_off; d.dst_off = img; d.I = I; d.KK = KK; d.ld = ld; d.transpose = transpose;
+      d.q_off = ks_off; d.j_off = 0; d.JT = ceil32(I); d.kind = 1;
+      p->prep2.push_back(d);
+    };
+    piece2(p->frag16_foldF, F0, voff, p->N * p->D, F0, 1, 0);                    // A[n][k] = V[k][n]
+    for (int b = 0; b < p->N; ++b)                                               // A[c][R + n] = V[b*D + c][n]
+      piece2(p->blocks[b].g16uf, p->D, voff + (int64_t)b * p->D * F0, F0, F0, 0, p->R / 16);
+  }
   return p;
 }
 
@@ -983,6 +1058,8 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_prep) (void)hipFree(p->d_prep);
   if (p->d_tdesc) (void)hipFree(p->d_tdesc);
   if (p->d_kdesc) (void)hipFree(p->d_kdesc);
+  if (p->d_prep2) (void)hipFree(p->d_prep2);
+  if (p->d_cov_fold) (void)hipFree(p->d_cov_fold);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->stack_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->phase_ev) if (e) (void)hipEventDestroy(e);
@@ -1123,11 +1200,11 @@ extern "C" int wn_debug_ws_region(const wn_plan* p, int32_t B, int32_t T, int32_
     case 0: if (in(L.H.size())) { *off = L.H[idx]; *len = rows * p->R; } break;
     case 1: if (in((size_t)p->N)) { *off = L.Z + (int64_t)idx * rows * p->Dp; *len = rows * p->Dp; } break;
     case 2: if (in(L.AG.size())) { *off = L.AG[idx]; *len = rows * p->D; } break;
-    case 3: *off = L.skipsum; *len = rows * p->Hin; break;
+    case 3: if (!fold_ok(p)) { *off = L.skipsum; *len = rows * p->Hin; } break;      // (folded training pass: never formed)
     case 4: if (in(L.HA.size())) { *off = L.HA[idx]; *len = rows * p->finals[idx].cout; } break;
     case 5: *off = L.logits; *len = rows * p->Cout; break;
     case 6: if (in(L.GF.size())) { *off = L.GF[idx]; *len = rows * p->finals[idx].cout; } break;
-    case 7: *off = L.g_skipsum; *len = rows * p->Hin; break;
+    case 7: if (!fold_ok(p)) { *off = L.g_skipsum; *len = rows * p->Hin; } break;
     case 8: if (in(L.GU.size())) { *off = L.GU[idx]; *len = rows * 2 * p->D; } break;
     case 9: if (in(L.GH.size())) { *off = L.GH[idx]; *len = rows * p->R; } break;
     case 10: *off = L.absmax; *len = L.n_absmax; break;
@@ -1165,6 +1242,7 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   if (bi.f16gate >= 0) { k.F16g = fragbase + bi.f16gate; k.F16r = fragbase + bi.conv1.frag16; }
   if (bi.g16u >= 0) k.G16u = fragbase + bi.g16u;
   if (bi.g16r >= 0) k.G16r = fragbase + bi.g16r;
+  if (bi.g16uf >= 0) k.G16uf = fragbase + bi.g16uf;
   if (p->LPB == 1 && bi.dil[0].frag16B >= 0) k.G16x = fragbase + bi.dil[0].frag16B;
   return k;
 }
@@ -1224,6 +1302,17 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     v.stride = p->N > 1 ? (p->tensors[(p->blocks[1].has_skip ? p->blocks[1].conv_skip : p->blocks[1].conv1).bias_t].off - v.off0) : 0;
     v.count = p->N; v.len = p->Sh; v.out = ws + L.bias_sum;
     rc = wn_launch_vecsum(v, s);
+    if (rc) return rc;
+  }
+  const bool fold = training && !rings && fold_ok(p);
+  if (fold && prep) {
+    const BlockInfo& b0 = p->blocks[0];
+    const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
+    rc = wn_launch_skip_fold(params, p->tensors[b0.conv_skip.kernel_t].off, wst, p->tensors[p->finals[0].kernel_t].off,
+                             p->tensors[p->finals[0].bias_t].off, ws + L.bias_sum, p->N, p->D, p->S, p->fold_F0, ws + L.vfold,
+                             ws + L.bfold, ws + L.wsall, s);
+    if (rc) return rc;
+    rc = wn_launch_prep_table(p->d_prep2, (int)p->prep2.size(), ws, fragbase, s);      // sources relative to the workspace
     if (rc) return rc;
   }
   // conditioning: mapping Dense stack + per-block time-invariant bias  (src/model.py:221-225,
@@ -1337,7 +1426,17 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   // skip sum folded into one contraction over all blocks' gated activations (src/model.py:235-236
   // with src/layers.py:216-219), or the last block output when use_skip is False
   const float* hin;
-  if (p->c.use_skip) {
+  size_t first_final = 0;
+  if (fold) {
+    // a = act(sum_b V(b)^T z_b + b'): the skip sum and the head's first conv in ONE contraction with F0 output columns
+    const ConvInfo& c0 = p->finals[0];
+    rc = Gemm(B, T, c0.cout, ceil32(c0.cout)).seg_planes(ws + L.Z, p->Dp, rows * p->Dp, p->N * p->Dp, nullptr)
+             .w16(fragbase + p->frag16_foldF).bias(ws + L.bfold).act(p->c.activation).absmax(nullptr, nullptr, fam)
+             .run(ws + L.HA[0], c0.cout, s);
+    if (rc) return rc;
+    hin = ws + L.HA[0];
+    first_final = 1;
+  } else if (p->c.use_skip) {
     rc = Gemm(B, T, p->Sh, ceil32(p->Sh)).seg_planes(ws + L.Z, p->Dp, rows * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
              .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
              .bias(ws + L.bias_sum).absmax(nullptr, nullptr, fam).run(ws + L.skipsum, p->Sh, s);
@@ -1348,8 +1447,8 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   }
   if (stack_prof) { (void)hipEventRecord(p->stack_ev[p->stack_used + 1], s); p->stack_used += 2; }
   // head, src/model.py:105-119,237-238: conv -> activation, last conv linear (softmax applied later)
-  int hc = p->Hin;
-  for (size_t i = 0; i < p->finals.size(); ++i) {
+  int hc = fold ? p->finals[0].cout : p->Hin;
+  for (size_t i = first_final; i < p->finals.size(); ++i) {
     const ConvInfo& c = p->finals[i];
     const bool last = (i + 1 == p->finals.size());
     float* dst = last ? ws + L.logits : ws + L.HA[i];
@@ -1426,12 +1525,13 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool pairk = !layerk && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
                      wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
                      wn_debug_get(13) != 1;
+  const bool fold = fold_ok(p);
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
   // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
   const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk) return WN_OK;
+      p->jobs_pairk == pairk && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
   std::vector<WnWgLayer> wgl;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
@@ -1492,7 +1592,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     }
     cover(c.kernel_t); cover(c.bias_t);
     cover(bi.conv1.kernel_t); cover(bi.conv1.bias_t);
-    if (bi.has_skip && p->c.use_skip) {
+    if (bi.has_skip && p->c.use_skip && !fold) {     // (folded: dW_s, db_s come out of M, see the weight-gradient phase)
       if (!skipk)
         add_jobs(jobs, zoff, p->Dp, p->D, 0, L.g_skipsum, p->S, p->S,
                  p->tensors[bi.conv_skip.kernel_t].off, p->tensors[bi.conv_skip.bias_t].off, am_skip);
@@ -1501,7 +1601,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   }
   p->head_first = (int)jobs.size();
   p->cov_head_first = (int)cov.size();
-  for (size_t i = 0; i < p->finals.size(); ++i) {
+  for (size_t i = fold ? 1 : 0; i < p->finals.size(); ++i) {      // (folded: the first conv's gradients come from M too)
     const ConvInfo& c = p->finals[i];
     const int64_t xin = (i == 0) ? (p->c.use_skip ? L.skipsum : L.H[p->N]) : L.HA[i - 1];
     if (headpairs) {
@@ -1552,6 +1652,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     }
   }
   p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
+  p->jobs_fold = fold;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
   p->jobs_skipk = skipk;
@@ -1707,8 +1808,9 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     rc = ensure_jobs(p, L, B, T);
     if (rc) return rc;
     // (the loss stage wrote d loss / d logits straight into GF.back(), the last final layer's g)
+    const bool fold = fold_ok(p);                  // (the forward pass of this call made the same decision)
     float* head_out = p->c.use_skip ? ws + L.g_skipsum : ws + L.GH[p->N];
-    for (int i = (int)p->finals.size() - 1; i >= 0; --i) {
+    for (int i = (int)p->finals.size() - 1; i >= (fold ? 1 : 0); --i) {
       const ConvInfo& c = p->finals[i];
       Gemm gm(B, T, c.cin, ceil32(c.cin));
       gm.seg(ws + L.GF[i], c.cout, c.cout, 0, fragbase + c.fragB);
@@ -1719,7 +1821,8 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       rc = gm.run(dst, c.cin, s);
       if (rc) return rc;
     }
-    const float* g_skip = p->c.use_skip ? ws + L.g_skipsum : nullptr;
+    // folded skip path: the gradient of the skip sum is never formed; the blocks contract dL/da = GF[0] with V(b)
+    const float* g_skip = (p->c.use_skip && !fold) ? ws + L.g_skipsum : nullptr;
     if (p->c.use_skip) {
       rc = wn_launch_fill(ws + L.GH[p->N], 0.f, rows * p->R, s);   // nothing flows into the last block output
       if (rc) return rc;
@@ -1770,6 +1873,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       bg.am_gskip = g_skip ? am_gskip : nullptr;
       bg.am_gu = am_GU(b); bg.am_gx = am_GH(b);
       if (have_gzs) { bg.gzs = ws + L.GZS + (int64_t)b * p->D; bg.ld_gzs = p->N * p->D; }
+      if (fold) { bg.g_fold = ws + L.GF[0]; bg.fold_F0 = p->fold_F0; bg.am_gfold = am_GF(0); }
       rc = block_backward(k, f, bg, s);
       if (rc) return rc;
       if (p->S == 0 && bg.g_xout == nullptr && g_skip) {
@@ -1842,7 +1946,32 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       rc = wn_launch_wgrad_layers(p->d_wgl, p->N, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
       if (rc) return rc;
     }
-    if (p->jobs_skipk) {
+    if (fold) {
+      // M = Z^T dL/da (N*D x F0) and colsum(dL/da) into their own slab, reduced, then the three small products
+      const int F0 = p->fold_F0;
+      const int64_t pm = (int64_t)p->N * p->D * F0 + F0;
+      rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.GF[0], F0, rows, p->N * p->D, F0, p->D, B * L.bsplits, ws + L.mslab, pm,
+                                0, (int64_t)p->D * F0, (int64_t)p->N * p->D * F0, 0, 1, am_GF(0), s);
+      if (rc) return rc;
+      rc = wn_launch_reduce_table(ws + L.mslab, B * L.bsplits, pm, ws + L.mtot, p->d_cov_fold, 1, s);
+      if (rc) return rc;
+      const BlockInfo& b0 = p->blocks[0];
+      const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
+      const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.bias_t].off - p->tensors[b0.conv_skip.bias_t].off : 0;
+      // Y = [M; colsum] W_f0^T -> dW_s of every block and db_s;  dW_f0 = [W_s(all); sum b_s]^T [M; colsum];  db_f0 = colsum
+      const ConvInfo& c0 = p->finals[0];
+      const int nd1 = p->N * p->D + 1;
+      const float* wf0 = params + p->tensors[c0.kernel_t].off;          // (1, S, F0): W_f0[s][n]
+      rc = wn_launch_sgemm_small(ws + L.mtot, F0, 1, wf0, 1, F0, ws + L.ytmp, p->S, nd1, p->S, F0, s);          // B[k = n][j = s]
+      if (rc) return rc;
+      // (a long-K product with a small output: the rows-contraction kernel splits K over workgroups)
+      rc = wgrad(ws + L.wsall, p->S, p->S, 0, ws + L.mtot, F0, F0, 1, nd1, grads + p->tensors[c0.kernel_t].off, nullptr, nullptr,
+                 slab, s);
+      if (rc) return rc;
+      rc = wn_launch_skip_scatter(ws + L.ytmp, ws + L.mtot + (int64_t)p->N * p->D * F0, p->tensors[b0.conv_skip.kernel_t].off, wst,
+                                  p->tensors[b0.conv_skip.bias_t].off, bst, p->tensors[c0.bias_t].off, p->N, p->D, p->S, F0, grads, s);
+      if (rc) return rc;
+    } else if (p->jobs_skipk) {
       const BlockInfo& b0 = p->blocks[0];
       const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
       const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.bias_t].off - p->tensors[b0.conv_skip.bias_t].off : 0;
