@@ -492,6 +492,33 @@ def test_weights_io_round_trip_with_optimizer_state(tmp_path):
     assert all(np.array_equal(w, d[f'w{i:03d}']) for i, w in enumerate(c.get_weights()))
 
 
+@pytest.mark.parametrize('name', ['cat_small_fused', 'cond', 'cat_lpb3'])
+def test_keras_weights_h5_round_trip(tmp_path, name):
+  """`.weights.h5` exchange files (train.py:149-154): export from one model, import into another -> identical
+  variables and identical logits; the tree carries the Keras-3 attribute paths."""
+  from wavenets_amd import WaveNet, io, h5
+  kw = dict(MODEL_CASES[name])
+  cond_inputs = kw.pop('cond_inputs', 0)
+  a = WaveNet(**kw, device=dev(), seed=11)
+  b = WaveNet(**kw, device=dev(), seed=12)
+  if cond_inputs:
+    a.build([(1, 8, 1), (1, cond_inputs)])
+    b.build([(1, 8, 1), (1, cond_inputs)])
+  path = str(tmp_path / io.checkpoint_name(4, 0.0005, 'h5'))
+  io.save_weights(a, path)
+  tree = h5.read_h5(path)
+  assert tree['causal']['vars']['0'].shape == (kw.get('kernel_size', 2), 1, kw['channels'])
+  assert len(tree['wavenet_blocks']) == kw['blocks']
+  assert len(tree['wavenet_blocks']['wave_net_layer']['dilated_stack']) == kw.get('layers_per_block', 1)
+  assert ('mapping' in tree) == (cond_inputs > 0)
+  io.load_weights(b, path)
+  assert torch.equal(a.flat_params.data, b.flat_params.data)
+  x, cond = _inputs(dict(kw, cond_inputs=cond_inputs), 2, 90, seed=1)
+  inp = (x.to(dev()), cond.to(dev())) if cond is not None else x.to(dev())
+  assert torch.equal(a.logits(inp), b.logits(inp))
+  assert io.find_resume(str(tmp_path)) == (path, 4, 0.0005)
+
+
 def test_categorical_samplers():
   kw = dict(MODEL_CASES['cat_small_fused'])
   ocfg, params, model = make_pair(seed=4, **kw)

@@ -32,6 +32,7 @@ config = {                       # defaults of the reference, train.py:22-50
     # additions of this driver
     'steps_per_epoch': 0, 'synthetic_utterances': 256, 'sample_rate': 16000, 'results_dir': './results',
     'preview_length': 0, 'condition_classes': 2, 'labels': None,
+    'checkpoint_format': 'npz',    # 'h5': Keras .weights.h5 exchange files (weights only, as the reference writes them)
 }
 
 
@@ -150,7 +151,8 @@ def main():
       if loss < best:                                               # ModelCheckpoint(save_best_only, monitor='loss')
         best = loss
         os.makedirs(run_dir, exist_ok=True)
-        io.save_weights(model, os.path.join(run_dir, io.checkpoint_name(epoch + 1, opt.learning_rate)), opt)
+        io.save_weights(model, os.path.join(run_dir, io.checkpoint_name(epoch + 1, opt.learning_rate,
+                                                                         config['checkpoint_format'])), opt)
     plateau.on_epoch_end(loss, opt)
     if stop or stopper.on_epoch_end(loss, model):
       break
