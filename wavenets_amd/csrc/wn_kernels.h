@@ -108,6 +108,23 @@ struct WnWgPair {
 int wn_wgrad_pair_kind(int K, int N);
 int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
                           int splits_per_b, hipStream_t s);
+// two products of the backward-data chain per launch: g_x(b+1) and, from it in registers, g_u(b) (wn_bwd_pair.hip)
+struct WnBwdPairArgs {
+  const float* gu_in;    // g_u(b+1) [rows][2D]
+  const float* gx_res;   // g_x(b+2) [rows][R]: the residual path's gradient
+  const float* gf;       // dL/da of the head's first conv [rows][F0] (folded skip path)
+  const float* ag;       // saved sigmoid of block b [rows][D]
+  const float* z; int32_t ldz;   // gated activations of block b
+  float* gx_out;         // g_x(b+1) [rows][R]
+  float* gu_out;         // g_u(b) [rows][2D]
+  const float* wx16;     // fp16 hi|lo image A[R][KS*2D] of block b+1's reversed conv
+  const float* wu16;     // fp16 hi|lo image A[D][R + F0] = [W_r(b) | V(b)]
+  const float* am_gu_in; const float* am_gf;    // running max-abs of g_u(b+1) / dL/da
+  float* am_gx; float* am_gu;                   // running max-abs of the two outputs
+  int32_t B, T, dil;     // dil = dilation of block b+1
+};
+int wn_bwd_pair_supported(int R, int D, int KS, int F0);
+int wn_launch_bwd_pair(const WnBwdPairArgs& a, hipStream_t s);
 // dW_s / db_s of the folded skip path for all blocks (wn_wgrad_skip.hip)
 int wn_wgrad_skip_supported(int D, int S, int KZ);
 int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64_t rows, int KZ, int S, int D,

@@ -1843,9 +1843,39 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         have_gzs = true;
       }
     }
+    // Two products per launch (wn_bwd_pair.hip): g_x(b+1) and, from it in registers, g_u(b).  The chain is then
+    //   g_u(N-1) | { g_x(b+1), g_u(b) } for b = N-2 .. 0 | g_x(0)   = N + 1 launches instead of 2 N.   knob 22 = 1: two launches per block
+    const bool pairk = fold && p->N >= 2 && p->drop_rate == 0.f && p->c.use_residual && (p->c.cond_inputs == 0 || cond_batched) && !have_gzs &&
+                       wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1 &&
+                       wn_debug_get(15) != 1;
     for (int b = p->N - 1; b >= 0; --b) {
       BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
       const BlockInfo& bi = p->blocks[b];
+      if (pairk && b < p->N - 1) {
+        const BlockPtrs k1 = block_ptrs(p, b + 1, params, fragbase, B, T);
+        WnBwdPairArgs a;
+        memset(&a, 0, sizeof(a));
+        a.gu_in = ws + L.GU[b + 1]; a.gx_res = ws + L.GH[b + 2]; a.gf = ws + L.GF[0];
+        a.ag = ws + L.AG[b]; a.z = ws + L.Z + (int64_t)b * rows * p->Dp; a.ldz = p->Dp;
+        a.gx_out = ws + L.GH[b + 1]; a.gu_out = ws + L.GU[b];
+        a.wx16 = k1.G16x; a.wu16 = k.G16uf;
+        a.am_gu_in = am_GU(b + 1); a.am_gf = am_GF(0); a.am_gx = am_GH(b + 1); a.am_gu = am_GU(b);
+        a.B = B; a.T = T; a.dil = k1.dil[0];
+        if (!a.wx16 || !a.wu16) { wn_set_error("bwd_pair: weight images missing"); return WN_E_UNSUPPORTED; }
+        rc = wn_launch_bwd_pair(a, s);
+        if (rc) return rc;
+        if (b == 0) {
+          // g_x(0): the gradient at the first block's input (only the input conv's weight gradients need it)
+          Gemm gm(B, T, p->R, ceil32(p->R));
+          for (int t = 0; t < p->KS; ++t)
+            gm.seg(ws + L.GU[0], 2 * p->D, 2 * p->D, -(p->KS - 1 - t) * k.dil[0], k.Bd[0] + t * k.Bd_stride[0]);
+          if (p->c.use_residual) gm.addc(ws + L.GH[1], p->R);
+          gm.w16(k.G16x).absmax(am_GU(0), nullptr, am_GH(0));
+          rc = gm.run(ws + L.GH[0], p->R, s);
+          if (rc) return rc;
+        }
+        continue;
+      }
       BlockBufs f;
       memset(&f, 0, sizeof(f));
       f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
@@ -1866,7 +1896,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       bg.g_skip = g_skip;
       bg.g_o_tmp = p->S == 0 ? ws + L.GO[b] : nullptr;
       bg.g_u = ws + L.GU[b];
-      bg.g_x = ws + L.GH[b];
+      bg.g_x = pairk ? nullptr : ws + L.GH[b];     // (pairs: the next launch forms g_x of this block)
       bg.dcb = (bi.has_cond && !cond_batched) ? ws + L.dcb : nullptr;
       bg.slab = slab;
       bg.am_gxout = bg.g_xout ? am_GH(b + 1) : nullptr;
