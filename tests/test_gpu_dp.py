@@ -19,6 +19,11 @@ pytestmark = pytest.mark.gpu
 
 KW = dict(blocks=6, channels=32, skip_channels=64, dilation_bound=8, final_layers_channels=[48, 40],
           activation='leaky_relu', bits=8, l2_reg_factor=0.001)
+# the shape family of the BASELINE networks (64 residual / 256 skip channels, first head conv 128 wide): training passes
+# fold the skip path into the head and run the two-products-per-launch backward chain
+KW_FOLDED = dict(blocks=5, channels=64, skip_channels=256, dilation_bound=16, final_layers_channels=[128, 64],
+                 activation='leaky_relu', bits=8, l2_reg_factor=0.001)
+KWS = {'small': KW, 'folded': KW_FOLDED}
 GLOBAL_B, T, STEPS = 4, 300, 3
 
 
@@ -44,7 +49,7 @@ def _run_steps(model, x):
   return logs
 
 
-def _worker(rank, world, port, backend, out_dir, dropout):
+def _worker(rank, world, port, backend, out_dir, dropout, net='small'):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -56,7 +61,7 @@ def _worker(rank, world, port, backend, out_dir, dropout):
   else:
     dist.init_process_group('gloo', rank=rank, world_size=world)
   from wavenets_amd import WaveNet, dp
-  model = WaveNet(**KW, dropout=dropout, device=dev, seed=7)
+  model = WaveNet(**KWS[net], dropout=dropout, device=dev, seed=7)
   x = _data()[dp.shard_rows(GLOBAL_B, world, rank)].to(dev)
   logs = _run_steps(model, x)
   torch.save({'params': model.flat_params.data.cpu(), 'logs': logs, 'drop_step': model._drop_step},
@@ -65,9 +70,9 @@ def _worker(rank, world, port, backend, out_dir, dropout):
   dist.destroy_process_group()
 
 
-def _check(tmp_path, backend, dropout=0.0):
+def _check(tmp_path, backend, dropout=0.0, net='small'):
   world = 2
-  mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), dropout), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), dropout, net), nprocs=world, join=True)
   r0 = torch.load(tmp_path / 'rank0.pt')
   r1 = torch.load(tmp_path / 'rank1.pt')
   assert torch.equal(r0['params'], r1['params'])                 # replicas stay bit-identical
@@ -76,14 +81,14 @@ def _check(tmp_path, backend, dropout=0.0):
   return r0
 
 
-@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
-def test_two_rank_train_step_equals_single_process(tmp_path, backend):
+@pytest.mark.parametrize('backend,net', [('gloo', 'small'), ('gloo', 'folded'), ('nccl', 'folded')])
+def test_two_rank_train_step_equals_single_process(tmp_path, backend, net):
   if backend == 'nccl' and torch.cuda.device_count() < 2:
     pytest.skip('needs 2 GPUs')
   from wavenets_amd import WaveNet
-  r0 = _check(tmp_path, backend)
+  r0 = _check(tmp_path, backend, net=net)
   dev = torch.device('cuda', 0)
-  single = WaveNet(**KW, device=dev, seed=7)
+  single = WaveNet(**KWS[net], device=dev, seed=7)
   logs = _run_steps(single, _data().to(dev))
   err = (single.flat_params.data.cpu() - r0['params']).abs().max().item()
   assert err < 1e-5, err
