@@ -20,8 +20,9 @@ batch 8, global batch 8 N -- global batch 64 at N = 8, as configs[2] names it).
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- SURVEY.md 8(d): the residual-block STACK forward.  achieved = N_blocks * 4 B T (2R + S) /
                   t_stack_fwd, t_stack_fwd = HIP events on the launch stream from the first block launch to the
-                  end of the folded skip contraction (the skip tensors of the reference's signature are produced
-                  there), against the 8 TB/s HBM3E peak.  "fused_block_kernel" beside it: the dominant kernel on
+                  end of the folded contraction over the blocks' gated activations (the skip tensors of the reference's
+                  signature are produced and consumed there; training passes fold the head's first conv into it),
+                  against the 8 TB/s HBM3E peak.  "fused_block_kernel" beside it: the dominant kernel on
                   its own counter bytes.
   cpu_baseline -- the CPU oracle (restated reference, PyTorch CPU) timed on this host's cores on a bounded
                   sample of the same workload
@@ -310,8 +311,9 @@ def main():
         'strong_scaling': strong_leg,
         'final_loss': logs['loss'],
         'roofline': {'bound': 'hbm',
-                     'kernel': 'residual-block stack forward: 30 x wn_layer_fwd_f16_kernel + the folded skip contraction '
-                               '(wn_gemm_rows16_wide_kernel), SURVEY.md 8(d)',
+                     'kernel': 'residual-block stack forward: 30 x wn_layer_fwd_f16_kernel + the folded contraction over all '
+                               "blocks' gated activations (wn_gemm_rows16_kernel<4>: skip sum and, in training passes, the head's "
+                               'first conv in one product), SURVEY.md 8(d)',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      'algorithmic_bytes_per_stack_pass': stack_bytes, 'algorithmic_bytes_per_block': bytes_layer,
@@ -323,7 +325,8 @@ def main():
                                             'mfma_busy_per_wave_cycle': mfma_busy},
                      'note': 'traffic = HBM bytes per launch of the fused block kernel (profiles/, FETCH x2 + WRITE); it '
                              'writes x_out, z and the saved sigmoid -- the skip tensors of the algorithmic signature are '
-                             'produced by the folded contraction inside the timed stack'},
+                             'consumed inside the folded contraction, which is part of the timed stack (and, folded with '
+                             "the head's first conv, does more than the 8(d) stack asks for)"},
     }
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args.cpu_budget)
