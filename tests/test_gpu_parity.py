@@ -776,11 +776,28 @@ def test_sound_callback_writes_ab_files(tmp_path):
   assert cb.on_epoch_end(0) is None                     # logged every 2nd epoch only
   cb.on_epoch_end(1)
   d = tmp_path / 'epoch_0001'
+  import wave
+  from wavenets_amd.callbacks import create_spectrogram
   for key in ('fast', 'standard'):
     wav = np.load(d / f'generated_{key}.npy')
     assert wav.shape == (5, 300, 1) and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
-    assert np.load(d / f'generated_spectrogram_{key}.npy').shape == (5, 129, 1, 1)
-    assert (d / f'generated_{key}_4.wav').exists()
+    # apply_mulaw=True: what is logged went through inverse_mu_law (src/callbacks.py:70-72,126-131): every value is the
+    # expansion of a left bin edge i / 128 - 1 of the 8-bit quantiser (src/model.py:411)
+    comp = np.sign(wav) * np.log1p(255.0 * np.abs(wav)) / np.log(256.0)
+    q = (comp + 1.0) * 128.0
+    assert np.abs(q - np.round(q)).max() < 1e-3 and q.min() >= -1e-3 and q.max() <= 255.001
+    spec = np.load(d / f'generated_spectrogram_{key}.npy')
+    assert spec.shape == (5, 129, 1, 1) and np.array_equal(spec, create_spectrogram(wav, 16000))
+    assert spec.min() == 0.0 and spec.max() == 1.0                       # min-max scaled over the batch (src/callbacks.py:151-157)
+    with wave.open(str(d / f'generated_{key}_4.wav'), 'rb') as f:
+      assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 16000, 300)
+      pcm = np.frombuffer(f.readframes(300), dtype='<i2').astype(np.float32) / 32768.0
+    assert np.abs(pcm - wav[4, :, 0]).max() <= 1.0 / 32768.0 + 1e-7
+  # a primed run (initial_sample given, src/callbacks.py:83-101): deterministic continuation is the same queued or not
+  x = O.synthetic_waveform(8, m.receptive_field, seed=2).to(dev())
+  a = m.generate(20, sample=x, use_queues=True, deterministic=True)
+  b = m.generate(20, sample=x, use_queues=False, deterministic=True)
+  assert torch.equal(a, b)
 
 
 # ------------------------------------------------------------------------------------------
