@@ -324,9 +324,11 @@ bool fold_ok(const wn_plan* p) {
 // in split-precision mode; knob 19 = 1 keeps them on the generic job table
 bool head_pairs_ok(const wn_plan* p) {
   if (p->finals.empty() || wn_debug_get(1) == 1 || wn_debug_get(3) == 1 || wn_debug_get(19) == 1) return false;
-  for (size_t i = fold_ok(p) ? 1 : 0; i < p->finals.size(); ++i)      // (folded: the first conv's gradients come from M)
-    if (wn_wgrad_pair_kind(p->finals[i].cin, p->finals[i].cout) == 0) return false;
-  return true;
+  // (folded: the first conv's gradients come from M.)  Layers without a pair kind -- e.g. the 30-column output conv of a
+  // mixture head -- stay on the generic job table, on the same compact slab
+  for (size_t i = fold_ok(p) ? 1 : 0; i < p->finals.size(); ++i)
+    if (wn_wgrad_pair_kind(p->finals[i].cin, p->finals[i].cout) != 0) return true;
+  return false;
 }
 
 WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
@@ -1604,7 +1606,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   for (size_t i = fold ? 1 : 0; i < p->finals.size(); ++i) {      // (folded: the first conv's gradients come from M too)
     const ConvInfo& c = p->finals[i];
     const int64_t xin = (i == 0) ? (p->c.use_skip ? L.skipsum : L.H[p->N]) : L.HA[i - 1];
-    if (headpairs) {
+    if (headpairs && wn_wgrad_pair_kind(c.cin, c.cout) != 0) {
       WnWgPair w;
       memset(&w, 0, sizeof(w));
       w.x_off = xin; w.g_off = L.GF[i]; w.shift = 0;

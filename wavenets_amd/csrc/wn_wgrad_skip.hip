@@ -201,6 +201,7 @@ int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64
     case 3: hipLaunchKernelGGL(wn_wgrad_skip_kernel<3>, grid, dim3(512), 0, s, a); break;
     case 4:
       if (ldz == 64 && ldg == 128) hipLaunchKernelGGL((wn_wgrad_skip_kernel<4, 64, 128>), grid, dim3(512), 0, s, a);
+      else if (ldz == 128 && ldg == 128) hipLaunchKernelGGL((wn_wgrad_skip_kernel<4, 128, 128>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL(wn_wgrad_skip_kernel<4>, grid, dim3(512), 0, s, a);
       break;
     case 5: hipLaunchKernelGGL(wn_wgrad_skip_kernel<5>, grid, dim3(512), 0, s, a); break;
