@@ -407,6 +407,228 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
   }
 }
 
+// Third form of the chain kernel (round 2): the same roles, phases and barriers as the first one, but the weights travel
+// in registers instead of an LDS image filled by LDS-DMA (see the comment at fetch_a).  Same MFMA sequences: bit-identical.
+template <int R32, int D32, int KS>
+__global__ __launch_bounds__(64 * (2 * D32 + R32 + 8)) void wn_gen_chain3_kernel(WnGenStepArgs a) {
+  using S = GnShape<R32, D32, KS>;
+  constexpr int R = S::R, D = S::D, JU = S::JU, KSR = S::KSR, KS0 = S::KS0, KS2 = S::KS2;
+  // LDS: only the exchange buffers -- u tiles (phase A -> B), x operands, z operands
+  constexpr int UB_BYTES = S::U0_BYTES;
+  constexpr int XOP_BYTES = KSR * 2048, ZOP_BYTES = KS2 * 2048;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[UB_BYTES + XOP_BYTES + ZOP_BYTES];
+  unsigned char* const ubuf = smem;
+  unsigned char* const xop = smem + UB_BYTES;
+  unsigned char* const zop = xop + XOP_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;                  // wave-uniform roles
+  const int tl = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x;
+  const int utt = tile * 32 + tl;
+  const bool live = utt < a.B;
+  const int ur = live ? utt : 0;
+  // roles: waves 0 .. JU-1 "chain" (phases A, B); JU .. JU+R32-1 "conv1" (carry the block input x, phase C);
+  // the rest "skip" (folded skip contraction).  Exclusive roles keep a wave's register set small: one fragment array and
+  // one 4 x float4 operand array serve all three (a 14-wave workgroup caps a lane at 128 registers).
+  const bool is_chain = wave < JU;
+  const bool is_conv1 = wave >= JU && wave < JU + R32;
+  const bool is_skip = wave >= JU + R32;
+  const int cw = wave - JU;                           // conv1 tile of a conv1 wave
+  const int sw = wave - JU - R32;                     // skip tile of a skip wave
+  const int nblocks = a.nblocks;
+
+  // Weights travel in REGISTERS: every chain wave fetches the newest tap's fragments and the u0 image of ITS tile, every
+  // conv1 wave the conv1 fragments and bias of its tile, every skip wave its skip fragments, for block b + 1 right after
+  // their last use in block b (the registers are dead from there to the same phase of the next block, ~1 block time: an
+  // L2 round trip).  No LDS-DMA, no weight image in LDS, no fragment reads from LDS.  Each role runs its OWN copy of the
+  // block loop (same barrier count) so that its registers are allocated apart from the other roles'.
+  // tile of fp32 values (this lane's 16 accumulators = two k-steps) -> hi|lo B operands of k-steps 2j, 2j+1
+  auto put_xop = [&](const f32x16& x, int j) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const f32x4 q0 = {x[8 * hf + 0], x[8 * hf + 1], x[8 * hf + 2], x[8 * hf + 3]};
+      const f32x4 q1 = {x[8 * hf + 4], x[8 * hf + 5], x[8 * hf + 6], x[8 * hf + 7]};
+      gn_h8 bh, bl;
+      gn_split8(q0, q1, bh, bl);
+      gn_h8* dst = reinterpret_cast<gn_h8*>(xop + (2 * j + hf) * 2048) + lane;
+      dst[0] = bh;
+      dst[64] = bl;
+    }
+  };
+
+  if (is_chain) {
+    // ================= chain waves: phase A (u tile `wave`) and phase B (z k-step `wave`) =================
+    gn_h8 wa[KSR][2];
+    f32x16 u;                                         // the u0 image of the tile, then u
+    auto fetch_a = [&](int b) {
+      const gn_h8* wd = reinterpret_cast<const gn_h8*>(a.ws + a.blocks[b].w16d_off) + (int64_t)KS0 * JU * 128 + lane;
+#pragma unroll
+      for (int kk = 0; kk < KSR; ++kk) {
+        wa[kk][0] = wd[((kk * JU + wave) * 2 + 0) * 64];
+        wa[kk][1] = wd[((kk * JU + wave) * 2 + 1) * 64];
+      }
+      const f32x4* u0 = reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * gridDim.x + tile) * (JU * 4) + wave * 4) * 64 + lane;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 v = u0[rq * 64];
+        u[4 * rq + 0] = v.x; u[4 * rq + 1] = v.y; u[4 * rq + 2] = v.z; u[4 * rq + 3] = v.w;
+      }
+    };
+    fetch_a(0);
+    GN_BARRIER();
+    const int jz = wave >> 1, rq0 = 2 * (wave & 1);
+    for (int b = 0; b < nblocks; ++b) {
+      const gn_h8* xl = reinterpret_cast<const gn_h8*>(xop) + lane;
+      wn_static_for<KSR>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        const gn_h8 bh = xl[(kk * 2 + 0) * 64];
+        const gn_h8 bl = xl[(kk * 2 + 1) * 64];
+        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kk][1], bh, u, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kk][0], bl, u, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kk][0], bh, u, 0, 0, 0);
+      });
+      f32x4* ub = reinterpret_cast<f32x4*>(ubuf) + (wave * 4) * 64 + lane;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
+      if (b + 1 < nblocks) fetch_a(b + 1);            // dead until phase A of block b + 1
+      GN_BARRIER();                                   // (1) u tiles visible
+      const f32x4* uf = reinterpret_cast<const f32x4*>(ubuf) + (jz * 4 + rq0) * 64 + lane;
+      const f32x4* ug = reinterpret_cast<const f32x4*>(ubuf) + ((jz + D32) * 4 + rq0) * 64 + lane;
+      const f32x4 f0 = uf[0], f1 = uf[64], g0 = ug[0], g1 = ug[64];
+      f32x4 z0, z1;
+      z0.x = wn_tanh_fast(f0.x) * wn_sigmoid_fast(g0.x); z0.y = wn_tanh_fast(f0.y) * wn_sigmoid_fast(g0.y);
+      z0.z = wn_tanh_fast(f0.z) * wn_sigmoid_fast(g0.z); z0.w = wn_tanh_fast(f0.w) * wn_sigmoid_fast(g0.w);
+      z1.x = wn_tanh_fast(f1.x) * wn_sigmoid_fast(g1.x); z1.y = wn_tanh_fast(f1.y) * wn_sigmoid_fast(g1.y);
+      z1.z = wn_tanh_fast(f1.z) * wn_sigmoid_fast(g1.z); z1.w = wn_tanh_fast(f1.w) * wn_sigmoid_fast(g1.w);
+      gn_h8 bh, bl;
+      gn_split8(z0, z1, bh, bl);
+      gn_h8* zd = reinterpret_cast<gn_h8*>(zop + wave * 2048) + lane;
+      zd[0] = bh;
+      zd[64] = bl;
+      GN_BARRIER();                                   // (2) z operands visible
+      if (live) {                                     // gated activations of this block (fire and forget)
+        float* zdst = a.ws + a.zrow_off + ((int64_t)b * a.B + utt) * D + 16 * wave + 4 * h;
+        *reinterpret_cast<f32x4*>(zdst) = z0;
+        *reinterpret_cast<f32x4*>(zdst + 8) = z1;
+      }
+      GN_BARRIER();                                   // (3) x operands visible, z operands free
+    }
+  } else if (is_conv1) {
+    // ================= conv1 waves: carry the block input x; phase C (o tile `cw`) =================
+    gn_h8 wc[KS2][2];
+    f32x16 o;                                         // the bias of the tile, then o
+    auto fetch_c = [&](int b) {
+      const gn_h8* wr = reinterpret_cast<const gn_h8*>(a.ws + a.blocks[b].w16r_off) + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        wc[ks][0] = wr[((ks * R32 + cw) * 2 + 0) * 64];
+        wc[ks][1] = wr[((ks * R32 + cw) * 2 + 1) * 64];
+      }
+      const float* br = a.params + a.blocks[b].bias_r_off + 32 * cw + 4 * h;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(br + 8 * rq);
+        o[4 * rq + 0] = v.x; o[4 * rq + 1] = v.y; o[4 * rq + 2] = v.z; o[4 * rq + 3] = v.w;
+      }
+    };
+    fetch_c(0);
+    // ---- input causal conv (C_in = 1): the k-ordered fma chain of the fp32 MFMA path, then + bias ----
+    f32x16 x;
+    {
+      float xs[KS];
+#pragma unroll
+      for (int t = 0; t < KS; ++t) xs[t] = a.xin[(int)((unsigned)((int)a.tau - (KS - 1 - t)) % (unsigned)KS) * a.B + ur];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * cw + wn_drow(r, h);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) acc = fmaf(a.causal_w[t * R + c], xs[t], acc);
+        x[r] = acc + a.causal_b[c];
+      }
+      put_xop(x, cw);
+    }
+    GN_BARRIER();
+    for (int b = 0; b < nblocks; ++b) {
+      if (live) {                                     // this block's input at time tau -> its ring
+        const WnGenBlock& cur = a.blocks[b];
+        float* dst = a.ws + cur.ring_off + ((int)((unsigned)(int)a.tau % (unsigned)cur.nslots) * a.B + utt) * R + 32 * cw + 4 * h;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
+      }
+      GN_BARRIER();                                   // (1)
+      GN_BARRIER();                                   // (2) z operands visible
+      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
+      wn_static_for<KS2>([&](auto kc) {
+        constexpr int ks = decltype(kc)::value;
+        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
+        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[ks][1], bh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[ks][0], bl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[ks][0], bh, o, 0, 0, 0);
+      });
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = a.residual ? o[r] + x[r] : o[r];
+      if (b + 1 < nblocks) {
+        put_xop(x, cw);
+        fetch_c(b + 1);                               // dead until phase C of block b + 1
+      }
+      GN_BARRIER();                                   // (3) x operands visible, z operands free
+    }
+    // ---- the last block output feeds the head when use_skip is False ----
+    if (a.hrow_off >= 0 && live) {
+      float* dst = a.ws + a.hrow_off + (int64_t)utt * R + 32 * cw + 4 * h;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
+    }
+  } else {
+    // ================= skip waves: acc += W_{s,b}^T z =================
+    gn_h8 wsk[KS2][2];
+    auto pre_skip = [&](int b) {
+      const gn_h8* wsi = reinterpret_cast<const gn_h8*>(a.ws + a.skip_w16_off) + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const int64_t blk = ((int64_t)(b * KS2 + ks) * a.skip_tiles + sw) * 2;
+        wsk[ks][0] = wsi[(blk + 0) * 64];
+        wsk[ks][1] = wsi[(blk + 1) * 64];
+      }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    pre_skip(0);
+    GN_BARRIER();
+    for (int b = 0; b < nblocks; ++b) {
+      GN_BARRIER();                                   // (1)
+      GN_BARRIER();                                   // (2) z operands visible
+      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
+        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][1], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bh, acc, 0, 0, 0);
+      }
+      if (b + 1 < nblocks) pre_skip(b + 1);           // next block's skip fragments (used one block later)
+      GN_BARRIER();                                   // (3)
+    }
+    // ---- folded skip sum + summed biases (the epilogue of the rows contraction it replaces) ----
+    if (live) {
+      const float* bs = a.ws + a.skip_bias_off + 32 * sw + 4 * h;
+      float* dst = a.ws + a.skiprow_off + (int64_t)utt * a.skip_ld + 32 * sw + 4 * h;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + 8 * rq);
+        *reinterpret_cast<f32x4*>(dst + 8 * rq) =
+            f32x4{acc[4 * rq + 0] + bv.x, acc[4 * rq + 1] + bv.y, acc[4 * rq + 2] + bv.z, acc[4 * rq + 3] + bv.w};
+      }
+    }
+  }
+}
+
 // The head of a queued-generation step -- up to WN_GEN_HEAD_MAX 1x1 convs with bias and activation
 // (src/model.py:105-119,237-238) -- for 32 utterances per workgroup in ONE launch instead of one launch
 // per layer.  Wave w owns column tile w of the current layer (all layers here have at most 8 tiles); a
@@ -535,7 +757,11 @@ template <int R32, int D32, int KS>
 static void gn_launch(const WnGenStepArgs& a, hipStream_t s) {
   const unsigned gx = (unsigned)((a.B + 31) / 32);
   hipLaunchKernelGGL((wn_gen_pre_kernel<R32, D32, KS>), dim3(gx, (unsigned)a.nblocks), dim3(64), 0, s, a);
-  hipLaunchKernelGGL((wn_gen_chain_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + a.skip_tiles)), 0, s, a);
+  // knob 23 = 1: the first form (weights through an LDS image filled by LDS-DMA)
+  if (wn_debug_get(23) != 1)
+    hipLaunchKernelGGL((wn_gen_chain3_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + R32 + a.skip_tiles)), 0, s, a);
+  else
+    hipLaunchKernelGGL((wn_gen_chain_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + a.skip_tiles)), 0, s, a);
 }
 
 int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, hipStream_t s) {
