@@ -105,6 +105,8 @@ uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step);   /* t
 int wn_debug_set(int key, int value);     /* kernel-variant switches of the CALLING THREAD (list: csrc/wn_error.cpp);
                                              key 1 = 1 selects the exact-fp32 MFMA kernels */
 int wn_debug_value(int key);              /* current value of a switch in the calling thread */
+int wn_debug_gen_ts(unsigned long long* out_96); /* switch 24: s_memtime stamps [role 3][block 4][phase 8] of the last
+                                             generation chain launch (profiling hook; -1 if none was taken) */
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
 int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
 /* test / diagnosis hook: float offset and length, inside the caller's TRAINING workspace for (B, T), of an

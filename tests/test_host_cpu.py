@@ -168,3 +168,33 @@ def test_condition_frames_follow_the_utterance_label():
   import pytest
   with pytest.raises(ValueError):
     data.preprocess_with_condition(x, 4, 4, 99, False)
+
+
+def test_generation_chain_prefetch_registers_are_untouched_until_their_wait():
+  """wn_gen.hip fetches weights with inline-asm loads and hand-placed s_waitcnt vmcnt(N) (the compiler's own placement
+  drains vmcnt at every use in a loop).  Nothing tells the compiler those registers are in flight, so a phi copy or a
+  reused temporary before the wait would read or clobber them: tools/check_gen_isa.py walks the kernel's control-flow
+  graph and must find no such instruction."""
+  import importlib.util, os, shutil
+  if not os.path.exists('/opt/rocm/bin/hipcc'):
+    pytest.skip('no hipcc')
+  path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'check_gen_isa.py')
+  spec = importlib.util.spec_from_file_location('check_gen_isa', path)
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  asm = mod.compile_asm()
+  lines = open(asm).read().split('\n')
+  import re
+  kernels, i = 0, 0
+  while i < len(lines):
+    m = re.match(r'^(_Z\d+wn_gen_chain3_kernel\w+):', lines[i])
+    if m:
+      j = i
+      while not lines[j].startswith('.Lfunc_end'):
+        j += 1
+      nloads, bad = mod.check_kernel(m.group(1), lines[i + 1:j])
+      assert nloads > 0 and bad == 0, (m.group(1), nloads, bad)
+      kernels += 1
+      i = j
+    i += 1
+  assert kernels >= 3

@@ -70,6 +70,7 @@ _SIGS = {
     'wn_plan_workspace_floats': (C.c_int64, [_P, C.c_int32, C.c_int32, C.c_int32]),
     'wn_debug_set': (C.c_int, [C.c_int, C.c_int]),
     'wn_debug_value': (C.c_int, [C.c_int]),
+    'wn_debug_gen_ts': (C.c_int, [_P]),
     'wn_plan_set_dropout': (C.c_int, [_P, C.c_float, C.c_uint64, C.c_uint64]),
     'wn_dropout_key_for': (C.c_uint32, [C.c_uint64, C.c_int32, C.c_uint64]),
     'wn_prof_enable': (C.c_int, [_P, C.c_int32]),

@@ -407,41 +407,73 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
   }
 }
 
-// Third form of the chain kernel (round 2): the same roles, phases and barriers as the first one, but the weights travel
-// in registers instead of an LDS image filled by LDS-DMA (see the comment at fetch_a).  Same MFMA sequences: bit-identical.
+// Chain kernel, second form: weights travel in REGISTERS, several blocks ahead.
+// A kernel starts with a cold L2 (the per-XCD L2s are invalidated at kernel boundaries), so every weight line of a
+// generation step comes from the memory side, ~2 us away -- about two blocks' worth of arithmetic.  One workgroup per 32
+// utterances, 2 waves per SIMD (256 registers a lane), three exclusive roles, each with its own copy of the block loop
+// (same barrier count) so that its registers are allocated apart from the others':
+//   chain wave w < JU      phase A: u tile w = u0 + W_{k-1}^T x; phase B: gated activation of z k-step w.  Holds the
+//                          newest-tap fragments and the u0 image of ITS tile for blocks b .. b+2.
+//   conv1 wave j < R / 32  carries the block input x; phase C: o tile j = b_r + W_r^T z, x_next = o (+ x).  Holds the
+//                          conv1 fragments and bias of its tile for blocks b .. b+2.
+//   skip wave s            two column tiles of the folded skip contraction, acc += W_{s,b}^T z (k order = block order):
+//                          tile 2s right after z_b is visible, tile 2s+1 one phase later (z operands are double-buffered)
+//                          while the chain waves are in their transcendental phase and the MFMA pipe is idle.
+// A workgroup's vector memory operations go through one 64 B / clock address pipe -- 128 KB of weights a block is ~2000
+// clocks of it, against ~2600 of arithmetic -- and a wave that issues into a full pipe stalls.  So no wave issues its
+// refill between its arithmetic and the barrier that ends its phase: the chain waves issue theirs in phase C (when they
+// idle), the conv1 waves in phase A, the skip waves in phases A and B.  LDS only holds the exchange
+// buffers (u tiles, x operands, 2 x z operands) and a copy of the block table.
+#define WN_GEN_CHAIN_MAX_BLOCKS 128
+// The prefetches are issued as inline asm and waited for by hand: the compiler's own s_waitcnt placement drains vmcnt to 0
+// at every use inside a loop, which would cut the distance of a 3-blocks-ahead fetch to one block.  vmcnt retires in
+// order, so "at most N younger operations outstanding" is exact as long as every iteration issues the same number of
+// vector memory operations -- the fetches past the last block are therefore still issued, all lanes on one line.
+__device__ __forceinline__ void gn_ld16(gn_h8& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gn_ld16(f32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gn_vmwait() { asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(N) : "memory"); }
+// ties a prefetched register to the wait before it: no use of `r` is scheduled above this point
+template <typename T>
+__device__ __forceinline__ void gn_landed(T& r) { asm volatile("" : "+v"(r)); }
 template <int R32, int D32, int KS>
-__global__ __launch_bounds__(64 * (2 * D32 + R32 + 8)) void wn_gen_chain3_kernel(WnGenStepArgs a) {
+__global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel(WnGenStepArgs a) {
   using S = GnShape<R32, D32, KS>;
   constexpr int R = S::R, D = S::D, JU = S::JU, KSR = S::KSR, KS0 = S::KS0, KS2 = S::KS2;
-  // LDS: only the exchange buffers -- u tiles (phase A -> B), x operands, z operands
+  constexpr int NS = 2;                               // register sets of the chain / conv1 waves (blocks in flight)
   constexpr int UB_BYTES = S::U0_BYTES;
   constexpr int XOP_BYTES = KSR * 2048, ZOP_BYTES = KS2 * 2048;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[UB_BYTES + XOP_BYTES + ZOP_BYTES];
+  constexpr int TBL_BYTES = WN_GEN_CHAIN_MAX_BLOCKS * (int)sizeof(WnGenBlock);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[UB_BYTES + XOP_BYTES + 2 * ZOP_BYTES + TBL_BYTES];
   unsigned char* const ubuf = smem;
   unsigned char* const xop = smem + UB_BYTES;
-  unsigned char* const zop = xop + XOP_BYTES;
+  unsigned char* const zop = xop + XOP_BYTES;         // z operands of block b in half b & 1
+  const WnGenBlock* const tbl = reinterpret_cast<const WnGenBlock*>(zop + 2 * ZOP_BYTES);   // valid after the first barrier
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;                  // wave-uniform roles
+  // roles are per wave: the wave index goes through an SGPR so that the role branches are scalar branches (the roles'
+  // code is then mutually exclusive for the compiler too, not a chain of exec-masked regions)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tl = lane & 31, h = lane >> 5;
   const int tile = blockIdx.x;
   const int utt = tile * 32 + tl;
   const bool live = utt < a.B;
   const int ur = live ? utt : 0;
-  // roles: waves 0 .. JU-1 "chain" (phases A, B); JU .. JU+R32-1 "conv1" (carry the block input x, phase C);
-  // the rest "skip" (folded skip contraction).  Exclusive roles keep a wave's register set small: one fragment array and
-  // one 4 x float4 operand array serve all three (a 14-wave workgroup caps a lane at 128 registers).
   const bool is_chain = wave < JU;
   const bool is_conv1 = wave >= JU && wave < JU + R32;
-  const bool is_skip = wave >= JU + R32;
   const int cw = wave - JU;                           // conv1 tile of a conv1 wave
-  const int sw = wave - JU - R32;                     // skip tile of a skip wave
+  const int sw = wave - JU - R32;                     // skip waves: column tiles 2 sw, 2 sw + 1
   const int nblocks = a.nblocks;
-
-  // Weights travel in REGISTERS: every chain wave fetches the newest tap's fragments and the u0 image of ITS tile, every
-  // conv1 wave the conv1 fragments and bias of its tile, every skip wave its skip fragments, for block b + 1 right after
-  // their last use in block b (the registers are dead from there to the same phase of the next block, ~1 block time: an
-  // L2 round trip).  No LDS-DMA, no weight image in LDS, no fragment reads from LDS.  Each role runs its OWN copy of the
-  // block loop (same barrier count) so that its registers are allocated apart from the other roles'.
+#define GN_TS(role, b, k) do { if (a.ts && lane == 0 && (b) >= 8 && (b) < 12) a.ts[((role) * 4 + (b) - 8) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  // block table -> LDS; every role calls this AFTER issuing its first fetches (one cold round trip for both)
+  auto copy_table = [&]() {
+    const int32_t* src = reinterpret_cast<const int32_t*>(a.blocks);
+    int32_t* dst = reinterpret_cast<int32_t*>(zop + 2 * ZOP_BYTES);
+    for (int i = threadIdx.x; i < nblocks * (int)(sizeof(WnGenBlock) / 4); i += blockDim.x) dst[i] = src[i];
+  };
   // tile of fp32 values (this lane's 16 accumulators = two k-steps) -> hi|lo B operands of k-steps 2j, 2j+1
   auto put_xop = [&](const f32x16& x, int j) {
 #pragma unroll
@@ -458,80 +490,137 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 8)) void wn_gen_chain3_kernel
 
   if (is_chain) {
     // ================= chain waves: phase A (u tile `wave`) and phase B (z k-step `wave`) =================
-    gn_h8 wa[KSR][2];
-    f32x16 u;                                         // the u0 image of the tile, then u
-    auto fetch_a = [&](int b) {
-      const gn_h8* wd = reinterpret_cast<const gn_h8*>(a.ws + a.blocks[b].w16d_off) + (int64_t)KS0 * JU * 128 + lane;
+    // per iteration: 2 KSR + 4 loads (fetch), then 2 stores (z row) -- see the wait in phase A
+    gn_h8 wa[NS][KSR][2];
+    f32x4 u0q[NS][4];                                 // the u0 images of the tile (dead columns read column 0's lines)
+    const int ulane = live ? lane : h * 32;
+    auto fetch_a = [&](auto sc, int b, int64_t w16d_off) {
+      constexpr int s = decltype(sc)::value;
+      const bool real = b < nblocks;                  // past the end: every lane on one line of the parameters
+      const gn_h8* wd = real ? reinterpret_cast<const gn_h8*>(a.ws + w16d_off) + (int64_t)KS0 * JU * 128 + lane
+                             : reinterpret_cast<const gn_h8*>(a.params);
+      const int m = real ? 64 : 0;
 #pragma unroll
       for (int kk = 0; kk < KSR; ++kk) {
-        wa[kk][0] = wd[((kk * JU + wave) * 2 + 0) * 64];
-        wa[kk][1] = wd[((kk * JU + wave) * 2 + 1) * 64];
+        gn_ld16(wa[s][kk][0], wd + ((kk * JU + wave) * 2 + 0) * m);
+        gn_ld16(wa[s][kk][1], wd + ((kk * JU + wave) * 2 + 1) * m);
       }
-      const f32x4* u0 = reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * gridDim.x + tile) * (JU * 4) + wave * 4) * 64 + lane;
+      const f32x4* u0 = real ? reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * gridDim.x + tile) * (JU * 4) + wave * 4) * 64 + ulane
+                             : reinterpret_cast<const f32x4*>(a.params);
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 v = u0[rq * 64];
-        u[4 * rq + 0] = v.x; u[4 * rq + 1] = v.y; u[4 * rq + 2] = v.z; u[4 * rq + 3] = v.w;
-      }
+      for (int rq = 0; rq < 4; ++rq) gn_ld16(u0q[s][rq], u0 + rq * m);
     };
-    fetch_a(0);
+    wn_static_for<NS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      fetch_a(sc, s, a.blk0[s].w16d_off);
+    });
+    // every first fetch has landed before the loop is entered (block 0 needs its set anyway): whatever copies the
+    // compiler places on the loop's entry edge then read settled registers
+    gn_vmwait<0>();
+    wn_static_for<NS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+#pragma unroll
+      for (int kk = 0; kk < KSR; ++kk) { gn_landed(wa[s][kk][0]); gn_landed(wa[s][kk][1]); }
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) gn_landed(u0q[s][rq]);
+    });
+    copy_table();
     GN_BARRIER();
     const int jz = wave >> 1, rq0 = 2 * (wave & 1);
-    for (int b = 0; b < nblocks; ++b) {
-      const gn_h8* xl = reinterpret_cast<const gn_h8*>(xop) + lane;
-      wn_static_for<KSR>([&](auto kc) {
-        constexpr int kk = decltype(kc)::value;
-        const gn_h8 bh = xl[(kk * 2 + 0) * 64];
-        const gn_h8 bl = xl[(kk * 2 + 1) * 64];
-        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kk][1], bh, u, 0, 0, 0);
-        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kk][0], bl, u, 0, 0, 0);
-        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kk][0], bh, u, 0, 0, 0);
-      });
-      f32x4* ub = reinterpret_cast<f32x4*>(ubuf) + (wave * 4) * 64 + lane;
+    for (int b0 = 0; b0 < nblocks; b0 += NS)
+      wn_static_for<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const int b = b0 + s;
+        if (b < nblocks) {
+          if (wave == 0) GN_TS(0, b, 0);
+          gn_vmwait<(NS - 1) * (2 * KSR + 4)>();
+          if (wave == 0) GN_TS(0, b, 1);
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
-      if (b + 1 < nblocks) fetch_a(b + 1);            // dead until phase A of block b + 1
-      GN_BARRIER();                                   // (1) u tiles visible
-      const f32x4* uf = reinterpret_cast<const f32x4*>(ubuf) + (jz * 4 + rq0) * 64 + lane;
-      const f32x4* ug = reinterpret_cast<const f32x4*>(ubuf) + ((jz + D32) * 4 + rq0) * 64 + lane;
-      const f32x4 f0 = uf[0], f1 = uf[64], g0 = ug[0], g1 = ug[64];
-      f32x4 z0, z1;
-      z0.x = wn_tanh_fast(f0.x) * wn_sigmoid_fast(g0.x); z0.y = wn_tanh_fast(f0.y) * wn_sigmoid_fast(g0.y);
-      z0.z = wn_tanh_fast(f0.z) * wn_sigmoid_fast(g0.z); z0.w = wn_tanh_fast(f0.w) * wn_sigmoid_fast(g0.w);
-      z1.x = wn_tanh_fast(f1.x) * wn_sigmoid_fast(g1.x); z1.y = wn_tanh_fast(f1.y) * wn_sigmoid_fast(g1.y);
-      z1.z = wn_tanh_fast(f1.z) * wn_sigmoid_fast(g1.z); z1.w = wn_tanh_fast(f1.w) * wn_sigmoid_fast(g1.w);
-      gn_h8 bh, bl;
-      gn_split8(z0, z1, bh, bl);
-      gn_h8* zd = reinterpret_cast<gn_h8*>(zop + wave * 2048) + lane;
-      zd[0] = bh;
-      zd[64] = bl;
-      GN_BARRIER();                                   // (2) z operands visible
-      if (live) {                                     // gated activations of this block (fire and forget)
-        float* zdst = a.ws + a.zrow_off + ((int64_t)b * a.B + utt) * D + 16 * wave + 4 * h;
-        *reinterpret_cast<f32x4*>(zdst) = z0;
-        *reinterpret_cast<f32x4*>(zdst + 8) = z1;
-      }
-      GN_BARRIER();                                   // (3) x operands visible, z operands free
-    }
-  } else if (is_conv1) {
+          for (int kk = 0; kk < KSR; ++kk) { gn_landed(wa[s][kk][0]); gn_landed(wa[s][kk][1]); }
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) gn_landed(u0q[s][rq]);
+          f32x16 u;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            u[4 * rq + 0] = u0q[s][rq].x; u[4 * rq + 1] = u0q[s][rq].y; u[4 * rq + 2] = u0q[s][rq].z; u[4 * rq + 3] = u0q[s][rq].w;
+          }
+          const gn_h8* xl = reinterpret_cast<const gn_h8*>(xop) + lane;
+          wn_static_for<KSR>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
+            const gn_h8 bh = xl[(kk * 2 + 0) * 64];
+            const gn_h8 bl = xl[(kk * 2 + 1) * 64];
+            u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s][kk][1], bh, u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s][kk][0], bl, u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s][kk][0], bh, u, 0, 0, 0);
+          });
+          f32x4* ub = reinterpret_cast<f32x4*>(ubuf) + (wave * 4) * 64 + lane;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
+          if (wave == 0) GN_TS(0, b, 2);
+          GN_BARRIER();                               // (1) u tiles visible
+          if (wave == 0) GN_TS(0, b, 3);
+          const f32x4* uf = reinterpret_cast<const f32x4*>(ubuf) + (jz * 4 + rq0) * 64 + lane;
+          const f32x4* ug = reinterpret_cast<const f32x4*>(ubuf) + ((jz + D32) * 4 + rq0) * 64 + lane;
+          const f32x4 f0 = uf[0], f1 = uf[64], g0 = ug[0], g1 = ug[64];
+          f32x4 z0, z1;
+          z0.x = wn_tanh_fast(f0.x) * wn_sigmoid_fast(g0.x); z0.y = wn_tanh_fast(f0.y) * wn_sigmoid_fast(g0.y);
+          z0.z = wn_tanh_fast(f0.z) * wn_sigmoid_fast(g0.z); z0.w = wn_tanh_fast(f0.w) * wn_sigmoid_fast(g0.w);
+          z1.x = wn_tanh_fast(f1.x) * wn_sigmoid_fast(g1.x); z1.y = wn_tanh_fast(f1.y) * wn_sigmoid_fast(g1.y);
+          z1.z = wn_tanh_fast(f1.z) * wn_sigmoid_fast(g1.z); z1.w = wn_tanh_fast(f1.w) * wn_sigmoid_fast(g1.w);
+          gn_h8 bh, bl;
+          gn_split8(z0, z1, bh, bl);
+          gn_h8* zd = reinterpret_cast<gn_h8*>(zop + (b & 1) * ZOP_BYTES + wave * 2048) + lane;
+          zd[0] = bh;
+          zd[64] = bl;
+          if (wave == 0) GN_TS(0, b, 4);
+          GN_BARRIER();                               // (2) z operands visible
+          if (wave == 0) GN_TS(0, b, 5);
+          // the chain waves idle through phase C: the refill of set s (dead until block b + NS) is issued HERE -- a wave
+          // that issues vector memory operations into a busy address pipeline stalls, which must not delay a barrier
+          fetch_a(sc, b + NS, tbl[min(b + NS, nblocks - 1)].w16d_off);
+          if (live) {                                 // gated activations of this block (fire and forget)
+            float* zdst = a.ws + a.zrow_off + ((int64_t)b * a.B + utt) * D + 16 * wave + 4 * h;
+            *reinterpret_cast<f32x4*>(zdst) = z0;
+            *reinterpret_cast<f32x4*>(zdst + 8) = z1;
+          }
+          if (wave == 0) GN_TS(0, b, 6);
+          GN_BARRIER();                               // (3) x operands visible
+          if (wave == 0) GN_TS(0, b, 7);
+        }
+      });
+    gn_vmwait<0>();                                   // the fetches past the last block: nothing may still be in flight
+  } else if (is_conv1) {                              // when their registers are reused
     // ================= conv1 waves: carry the block input x; phase C (o tile `cw`) =================
-    gn_h8 wc[KS2][2];
-    f32x16 o;                                         // the bias of the tile, then o
-    auto fetch_c = [&](int b) {
-      const gn_h8* wr = reinterpret_cast<const gn_h8*>(a.ws + a.blocks[b].w16r_off) + lane;
+    // per iteration: 4 stores (ring) at the top, 2 KS2 + 4 loads (fetch) at the bottom -- see the wait in phase C
+    gn_h8 wc[NS][KS2][2];
+    f32x4 bq[NS][4];                                  // the bias of the tile as an accumulator image
+    auto fetch_c = [&](auto sc, bool real, int64_t w16r_off, int64_t bias_r_off) {
+      constexpr int s = decltype(sc)::value;
+      const gn_h8* wr = real ? reinterpret_cast<const gn_h8*>(a.ws + w16r_off) + lane : reinterpret_cast<const gn_h8*>(a.params);
+      const int m = real ? 64 : 0;
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
-        wc[ks][0] = wr[((ks * R32 + cw) * 2 + 0) * 64];
-        wc[ks][1] = wr[((ks * R32 + cw) * 2 + 1) * 64];
+        gn_ld16(wc[s][ks][0], wr + ((ks * R32 + cw) * 2 + 0) * m);
+        gn_ld16(wc[s][ks][1], wr + ((ks * R32 + cw) * 2 + 1) * m);
       }
-      const float* br = a.params + a.blocks[b].bias_r_off + 32 * cw + 4 * h;
+      const float* br = real ? a.params + bias_r_off + 32 * cw + 4 * h : a.params;
+      const int mb = real ? 8 : 0;
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(br + 8 * rq);
-        o[4 * rq + 0] = v.x; o[4 * rq + 1] = v.y; o[4 * rq + 2] = v.z; o[4 * rq + 3] = v.w;
-      }
+      for (int rq = 0; rq < 4; ++rq) gn_ld16(bq[s][rq], br + mb * rq);
     };
-    fetch_c(0);
+    wn_static_for<NS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      fetch_c(sc, s < nblocks, a.blk0[s].w16r_off, a.blk0[s].bias_r_off);
+    });
+    gn_vmwait<0>();                                   // as in the chain role
+    wn_static_for<NS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) { gn_landed(wc[s][ks][0]); gn_landed(wc[s][ks][1]); }
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) gn_landed(bq[s][rq]);
+    });
+    copy_table();
     // ---- input causal conv (C_in = 1): the k-ordered fma chain of the fp32 MFMA path, then + bias ----
     f32x16 x;
     {
@@ -549,33 +638,57 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 8)) void wn_gen_chain3_kernel
       put_xop(x, cw);
     }
     GN_BARRIER();
-    for (int b = 0; b < nblocks; ++b) {
-      if (live) {                                     // this block's input at time tau -> its ring
-        const WnGenBlock& cur = a.blocks[b];
-        float* dst = a.ws + cur.ring_off + ((int)((unsigned)(int)a.tau % (unsigned)cur.nslots) * a.B + utt) * R + 32 * cw + 4 * h;
+    for (int b0 = 0; b0 < nblocks; b0 += NS)
+      wn_static_for<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const int b = b0 + s;
+        if (b < nblocks) {
+          if (live) {                                 // this block's input at time tau -> its ring
+            const WnGenBlock& cur = tbl[b];
+            float* dst = a.ws + cur.ring_off + ((int)((unsigned)(int)a.tau % (unsigned)cur.nslots) * a.B + utt) * R + 32 * cw + 4 * h;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-          *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
-      }
-      GN_BARRIER();                                   // (1)
-      GN_BARRIER();                                   // (2) z operands visible
-      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
-      wn_static_for<KS2>([&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
-        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[ks][1], bh, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[ks][0], bl, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[ks][0], bh, o, 0, 0, 0);
+            for (int rq = 0; rq < 4; ++rq)
+              *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
+          }
+          if (cw == 0) GN_TS(1, b, 0);
+          GN_BARRIER();                               // (1)
+          if (cw == 0) GN_TS(1, b, 1);
+          GN_BARRIER();                               // (2) z operands visible
+          if (cw == 0) GN_TS(1, b, 2);
+          gn_vmwait<(NS - 1) * (2 * KS2 + 4)>();   // only LOADS count as younger: stores retire out of order with them
+          if (cw == 0) GN_TS(1, b, 3);
+#pragma unroll
+          for (int ks = 0; ks < KS2; ++ks) { gn_landed(wc[s][ks][0]); gn_landed(wc[s][ks][1]); }
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) gn_landed(bq[s][rq]);
+          f32x16 o;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            o[4 * rq + 0] = bq[s][rq].x; o[4 * rq + 1] = bq[s][rq].y; o[4 * rq + 2] = bq[s][rq].z; o[4 * rq + 3] = bq[s][rq].w;
+          }
+          const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop + (b & 1) * ZOP_BYTES) + lane;
+          wn_static_for<KS2>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            const gn_h8 bh = zl[(ks * 2 + 0) * 64];
+            const gn_h8 bl = zl[(ks * 2 + 1) * 64];
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[s][ks][1], bh, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[s][ks][0], bl, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[s][ks][0], bh, o, 0, 0, 0);
+          });
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = a.residual ? o[r] + x[r] : o[r];
+          if (b + 1 < nblocks) put_xop(x, cw);
+          if (cw == 0) GN_TS(1, b, 4);
+          GN_BARRIER();                               // (3) x operands visible
+          if (cw == 0) GN_TS(1, b, 5);
+          {                                           // refill of set s, issued while the conv1 waves idle (phases A, B)
+            const WnGenBlock& nb = tbl[min(b + NS, nblocks - 1)];
+            fetch_c(sc, b + NS < nblocks, nb.w16r_off, nb.bias_r_off);
+          }
+          if (cw == 0) GN_TS(1, b, 6);
+        }
       });
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[r] = a.residual ? o[r] + x[r] : o[r];
-      if (b + 1 < nblocks) {
-        put_xop(x, cw);
-        fetch_c(b + 1);                               // dead until phase C of block b + 1
-      }
-      GN_BARRIER();                                   // (3) x operands visible, z operands free
-    }
+    gn_vmwait<0>();                                   // the fetches past the last block
     // ---- the last block output feeds the head when use_skip is False ----
     if (a.hrow_off >= 0 && live) {
       float* dst = a.ws + a.hrow_off + (int64_t)utt * R + 32 * cw + 4 * h;
@@ -584,47 +697,114 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 8)) void wn_gen_chain3_kernel
         *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
     }
   } else {
-    // ================= skip waves: acc += W_{s,b}^T z =================
-    gn_h8 wsk[KS2][2];
-    auto pre_skip = [&](int b) {
-      const gn_h8* wsi = reinterpret_cast<const gn_h8*>(a.ws + a.skip_w16_off) + lane;
+    // ================= skip waves: acc_t += W_{s,b}^T z for column tiles t0 = 2 sw and t1 = 2 sw + 1 =================
+    // Two register sets per tile (set = block parity).  Tile t0 of block b runs between barriers (2) and (3) of block b,
+    // tile t1 between (1) and (2) of block b + 1 -- z_b stays valid there because the z operands are double-buffered.
+    const int t0 = 2 * sw, t1 = 2 * sw + 1;
+    const bool has1 = t1 < a.skip_tiles;
+    gn_h8 w0[KS2][2], w1[KS2][2];
+    // vector memory operations of a skip wave: 2 KS2 loads per pre_skip, always issued (see the waits)
+    auto pre_skip = [&](gn_h8 (&w)[KS2][2], int b, int t) {
+      const bool real = b < nblocks;
+      const gn_h8* wsi = real ? reinterpret_cast<const gn_h8*>(a.ws + a.skip_w16_off) + lane : reinterpret_cast<const gn_h8*>(a.params);
+      const int64_t m = real ? 64 : 0;
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
-        const int64_t blk = ((int64_t)(b * KS2 + ks) * a.skip_tiles + sw) * 2;
-        wsk[ks][0] = wsi[(blk + 0) * 64];
-        wsk[ks][1] = wsi[(blk + 1) * 64];
+        const int64_t blk = ((int64_t)(b * KS2 + ks) * a.skip_tiles + t) * 2;
+        gn_ld16(w[ks][0], wsi + (blk + 0) * m);
+        gn_ld16(w[ks][1], wsi + (blk + 1) * m);
       }
     };
-    f32x16 acc;
+    // the other tile's fetch (if there is a second tile) is the only younger operation
+    auto landed = [&](gn_h8 (&w)[KS2][2]) {
+      if (has1) gn_vmwait<2 * KS2>(); else gn_vmwait<0>();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    pre_skip(0);
-    GN_BARRIER();
-    for (int b = 0; b < nblocks; ++b) {
-      GN_BARRIER();                                   // (1)
-      GN_BARRIER();                                   // (2) z operands visible
-      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
+      for (int ks = 0; ks < KS2; ++ks) { gn_landed(w[ks][0]); gn_landed(w[ks][1]); }
+    };
+    auto mac = [&](f32x16& acc, const gn_h8 (&w)[KS2][2], int half) {
+      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop + half * ZOP_BYTES) + lane;
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
         const gn_h8 bh = zl[(ks * 2 + 0) * 64];
         const gn_h8 bl = zl[(ks * 2 + 1) * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][1], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][1], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][0], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][0], bh, acc, 0, 0, 0);
       }
-      if (b + 1 < nblocks) pre_skip(b + 1);           // next block's skip fragments (used one block later)
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // The two loops below contain no conditional fetch: a fetch under a branch makes the fetched registers a phi of two
+    // definitions, and the copies that resolve it would read registers whose load is still in flight.
+    pre_skip(w0, 0, t0);
+    auto settle = [&](gn_h8 (&w)[KS2][2]) {          // as in the chain role
+      gn_vmwait<0>();
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) { gn_landed(w[ks][0]); gn_landed(w[ks][1]); }
+    };
+    if (has1) {
+      pre_skip(w1, 0, t1);
+      settle(w0);
+      settle(w1);
+      copy_table();
+      GN_BARRIER();
+      GN_BARRIER();                                   // (1) of block 0
+      GN_BARRIER();                                   // (2)
+      landed(w0);
+      mac(acc0, w0, 0);
       GN_BARRIER();                                   // (3)
+      pre_skip(w0, 1, t0);
+      for (int b = 1; b < nblocks; ++b) {
+        if (sw == 0) GN_TS(2, b, 0);
+        GN_BARRIER();                                 // (1)
+        if (sw == 0) GN_TS(2, b, 1);
+        landed(w1);                                   // tile t1 of block b - 1, then its refill (phase B: the address pipe is idle)
+        if (sw == 0) GN_TS(2, b, 2);
+        mac(acc1, w1, (b - 1) & 1);
+        pre_skip(w1, b, t1);
+        if (sw == 0) GN_TS(2, b, 3);
+        GN_BARRIER();                                 // (2) z operands of block b visible
+        if (sw == 0) GN_TS(2, b, 4);
+        landed(w0);
+        mac(acc0, w0, b & 1);
+        if (sw == 0) GN_TS(2, b, 5);
+        GN_BARRIER();                                 // (3)
+        if (sw == 0) GN_TS(2, b, 6);
+        pre_skip(w0, b + 1, t0);                      // refill in phase A, not in phase C where the chain waves issue theirs
+        if (sw == 0) GN_TS(2, b, 7);
+      }
+      gn_vmwait<0>();                                 // also the fetches past the last block
+      landed(w1);                                     // tile t1 of the last block (its z half is not rewritten)
+      mac(acc1, w1, (nblocks - 1) & 1);
+    } else {
+      settle(w0);
+      copy_table();
+      GN_BARRIER();
+      for (int b = 0; b < nblocks; ++b) {
+        GN_BARRIER();                                 // (1)
+        GN_BARRIER();                                 // (2) z operands of block b visible
+        landed(w0);
+        mac(acc0, w0, b & 1);
+        GN_BARRIER();                                 // (3)
+        pre_skip(w0, b + 1, t0);
+      }
+      gn_vmwait<0>();                                 // the fetch past the last block
     }
     // ---- folded skip sum + summed biases (the epilogue of the rows contraction it replaces) ----
     if (live) {
-      const float* bs = a.ws + a.skip_bias_off + 32 * sw + 4 * h;
-      float* dst = a.ws + a.skiprow_off + (int64_t)utt * a.skip_ld + 32 * sw + 4 * h;
+      auto put = [&](const f32x16& acc, int t) {
+        const float* bsp = a.ws + a.skip_bias_off + 32 * t + 4 * h;
+        float* dst = a.ws + a.skiprow_off + (int64_t)utt * a.skip_ld + 32 * t + 4 * h;
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + 8 * rq);
-        *reinterpret_cast<f32x4*>(dst + 8 * rq) =
-            f32x4{acc[4 * rq + 0] + bv.x, acc[4 * rq + 1] + bv.y, acc[4 * rq + 2] + bv.z, acc[4 * rq + 3] + bv.w};
-      }
+        for (int rq = 0; rq < 4; ++rq) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bsp + 8 * rq);
+          *reinterpret_cast<f32x4*>(dst + 8 * rq) =
+              f32x4{acc[4 * rq + 0] + bv.x, acc[4 * rq + 1] + bv.y, acc[4 * rq + 2] + bv.z, acc[4 * rq + 3] + bv.w};
+        }
+      };
+      put(acc0, t0);
+      if (has1) put(acc1, t1);
     }
   }
 }
@@ -753,13 +933,25 @@ int64_t wn_gen_u0_floats(int B, int nblocks, int D) {
   return (int64_t)nblocks * ((B + 31) / 32) * (2 * D / 32) * 1024;
 }
 
+static unsigned long long* g_gen_ts = nullptr;
+static unsigned long long* wn_gen_ts_buffer() {
+  if (!g_gen_ts) { (void)hipMalloc((void**)&g_gen_ts, 3 * 4 * 8 * 8); (void)hipMemset(g_gen_ts, 0, 3 * 4 * 8 * 8); }
+  return g_gen_ts;
+}
+extern "C" int wn_debug_gen_ts(unsigned long long* out) {
+  if (!g_gen_ts) return -1;
+  return (int)hipMemcpy(out, g_gen_ts, 3 * 4 * 8 * 8, hipMemcpyDeviceToHost);
+}
 template <int R32, int D32, int KS>
 static void gn_launch(const WnGenStepArgs& a, hipStream_t s) {
   const unsigned gx = (unsigned)((a.B + 31) / 32);
   hipLaunchKernelGGL((wn_gen_pre_kernel<R32, D32, KS>), dim3(gx, (unsigned)a.nblocks), dim3(64), 0, s, a);
-  // knob 23 = 1: the first form (weights through an LDS image filled by LDS-DMA)
-  if (wn_debug_get(23) != 1)
-    hipLaunchKernelGGL((wn_gen_chain3_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + R32 + a.skip_tiles)), 0, s, a);
+  // knob 23 = 1 or a very deep stack: the first form (weights through an LDS image filled by LDS-DMA)
+  if (wn_debug_get(23) != 1 && a.nblocks <= WN_GEN_CHAIN_MAX_BLOCKS) {
+    WnGenStepArgs a2 = a;
+    a2.ts = wn_debug_get(24) ? wn_gen_ts_buffer() : nullptr;
+    hipLaunchKernelGGL((wn_gen_chain3_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + R32 + (a.skip_tiles + 1) / 2)), 0, s, a2);
+  }
   else
     hipLaunchKernelGGL((wn_gen_chain_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + a.skip_tiles)), 0, s, a);
 }

@@ -194,6 +194,9 @@ struct WnGenStepArgs {
   int64_t u0_off;                  // [N][tiles][2D/32 * 1024] partial gated-conv accumulators (pre kernel -> chain)
   int64_t tau;
   int32_t B, nblocks, residual;
+  int32_t pad_;
+  unsigned long long* ts;          // TIMING EXPERIMENT
+  WnGenBlock blk0[3];              // blocks[0..2] by value (the first fetches do not wait for the table)
 };
 // the head of a generation step in one launch (wn_gen.hip)
 #define WN_GEN_HEAD_MAX 4

@@ -109,6 +109,7 @@ struct wn_plan {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int head_first = 0, cov_head_first = 0;   // job / coverage tables: the head's entries come last
   WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
+  WnGenBlock gen_blk0[3]{};
   int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
@@ -2379,6 +2380,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     WN_HIP_CHECK(hipMalloc((void**)&p->d_gen, tab.size() * sizeof(WnGenBlock)));
     WN_HIP_CHECK(hipMemcpy(p->d_gen, tab.data(), tab.size() * sizeof(WnGenBlock), hipMemcpyHostToDevice));
     p->gen_B = B;
+    for (int b = 0; b < 3; ++b) p->gen_blk0[b] = tab[std::min(b, p->N - 1)];
   }
   for (int step = 1; step < length; ++step) {
     const int64_t tau = (int64_t)RF + step - 1;        // time of the newest known sample
@@ -2389,6 +2391,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       ga.causal_w = params + p->tensors[p->causal.kernel_t].off;
       ga.causal_b = params + p->tensors[p->causal.bias_t].off;
       ga.u0_off = G.u0;
+      for (int b = 0; b < 3; ++b) ga.blk0[b] = p->gen_blk0[b];
       if (skip_in_chain) {
         ga.skip_w16_off = G.prime + L.frag + p->frag16_skipF;
         ga.skip_bias_off = G.prime + L.bias_sum;
