@@ -16,8 +16,10 @@ SRC = os.path.join(HERE, '..', 'wavenets_amd', 'csrc', 'wn_gen.hip')
 
 def compile_asm():
   out = '/tmp/wn_gen_check.s'
-  subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=on', '-S',
-                         '--cuda-device-only', SRC, '-o', out])
+  flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=on', '--cuda-device-only']
+  subprocess.check_call(['/opt/rocm/bin/hipcc'] + flags + ['-S', SRC, '-o', out])
+  # -S does not assemble the inline asm: a bad operand only shows when the object is produced
+  subprocess.check_call(['/opt/rocm/bin/hipcc'] + flags + ['-c', SRC, '-o', '/tmp/wn_gen_check.o'])
   return out
 
 
@@ -64,7 +66,9 @@ def check_kernel(name, body):
       continue
     nloads += 1
     dest = set(regs(t.split(',')[0]))
-    seen, stack = set(), list(succ(i))
+    seen, stack, pred = set(), [], {}
+    for n in succ(i):
+      pred.setdefault(n, i); stack.append(n)
     while stack:
       j = stack.pop()
       if j in seen:
@@ -79,10 +83,18 @@ def check_kernel(name, body):
         # the same registers fetched again before any use (tail dummy fetch after the last block): fine, keep walking
         pass
       elif dest & set(regs(tj)):
-        print(f'{name}: instruction {j} "{tj}" touches {sorted(dest & set(regs(tj)))} of the load at {i} "{t}" before a wait')
+        path, q = [], j
+        while q != i:
+          q = pred[q]
+          if ins[q][0].split()[0] in ('s_branch',) or ins[q][0].startswith('s_cbranch'):
+            path.append(f'{q}:{ins[q][0]}')
+        print(f'{name}: instruction {j} "{tj}" touches {sorted(dest & set(regs(tj)))} of the load at {i} "{t}" before a wait'
+              f' (branches on the way: {" <- ".join(path[:12])})')
         bad += 1
         continue
-      stack += succ(j)
+      for n in succ(j):
+        if n not in seen:
+          pred.setdefault(n, j); stack.append(n)
   return nloads, bad
 
 

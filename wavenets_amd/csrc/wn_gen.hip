@@ -402,7 +402,8 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
     for (int rq = 0; rq < 4; ++rq) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + 8 * rq);
       *reinterpret_cast<f32x4*>(dst + 8 * rq) =
-          f32x4{carry[4 * rq + 0] + bv.x, carry[4 * rq + 1] + bv.y, carry[4 * rq + 2] + bv.z, carry[4 * rq + 3] + bv.w};
+          f32x4{wn_act(carry[4 * rq + 0] + bv.x, a.skip_act), wn_act(carry[4 * rq + 1] + bv.y, a.skip_act),
+                wn_act(carry[4 * rq + 2] + bv.z, a.skip_act), wn_act(carry[4 * rq + 3] + bv.w, a.skip_act)};
     }
   }
 }
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
 // idle), the conv1 waves in phase A, the skip waves in phases A and B.  LDS only holds the exchange
 // buffers (u tiles, x operands, 2 x z operands) and a copy of the block table.
 #define WN_GEN_CHAIN_MAX_BLOCKS 128
+#define WN_GEN_HELPERS_PER_XCD 2
 // The prefetches are issued as inline asm and waited for by hand: the compiler's own s_waitcnt placement drains vmcnt to 0
 // at every use inside a loop, which would cut the distance of a 3-blocks-ahead fetch to one block.  vmcnt retires in
 // order, so "at most N younger operations outstanding" is exact as long as every iteration issues the same number of
@@ -467,6 +469,42 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
   const int cw = wave - JU;                           // conv1 tile of a conv1 wave
   const int sw = wave - JU - R32;                     // skip waves: column tiles 2 sw, 2 sw + 1
   const int nblocks = a.nblocks;
+  if ((int)blockIdx.x >= a.ntiles) {
+    // ---- helper workgroup: pulls the step's weight images into its XCD's L2 ----
+    // L2 is cold at kernel start and a single CU keeps only so many misses in flight: the chain workgroup alone draws its
+    // ~3.8 MB at ~65 GB/s, which is what bounds a step.  Workgroups go to the 8 XCDs round-robin by index, so the helpers
+    // whose index is congruent to a chain workgroup's share its L2: they touch every 128 B line of every block's images in
+    // block order (LDS-DMA dwords into a landing pad: no destination registers, nothing to wait for) and leave.  The chain
+    // workgroup's own fetches then hit L2, or merge with a miss that is already on its way.
+    const int hj = (int)blockIdx.x - a.ntiles, xcd = (int)blockIdx.x & 7, rank = hj >> 3;
+    if (xcd >= a.ntiles) return;                      // no chain workgroup on this XCD
+    int32_t* tb = reinterpret_cast<int32_t*>(zop + 2 * ZOP_BYTES);
+    {
+      const int32_t* src = reinterpret_cast<const int32_t*>(a.blocks);
+      for (int i = threadIdx.x; i < nblocks * (int)(sizeof(WnGenBlock) / 4); i += blockDim.x) tb[i] = src[i];
+    }
+    __syncthreads();
+    const int nw = (int)(blockDim.x >> 6);
+    const int stride = WN_GEN_HELPERS_PER_XCD * nw * 64;          // lanes of all helpers of this XCD
+    const int g0 = (rank * nw + wave) * 64 + lane;
+    auto touch = [&](const void* base, int bytes) {
+      const char* p = reinterpret_cast<const char*>(base);
+      for (int l = g0; l * 128 < bytes; l += stride)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + (int64_t)l * 128),
+                                         (__attribute__((address_space(3))) void*)ubuf, 4, 0, 0);
+    };
+    for (int b = 0; b < nblocks; ++b) {
+      const WnGenBlock& nb = tbl[b];
+      touch(reinterpret_cast<const char*>(a.ws + nb.w16d_off) + (int64_t)KS0 * JU * 2048, KSR * JU * 2048);
+      for (int t = xcd; t < a.ntiles; t += 8)
+        touch(a.ws + a.u0_off + ((int64_t)b * a.ntiles + t) * (JU * 1024), JU * 4096);
+      touch(a.ws + nb.w16r_off, KS2 * R32 * 2048);
+      touch(a.params + nb.bias_r_off, R * 4);
+      if (a.skip_tiles > 0)
+        touch(reinterpret_cast<const char*>(a.ws + a.skip_w16_off) + (int64_t)b * KS2 * a.skip_tiles * 2048, KS2 * a.skip_tiles * 2048);
+    }
+    return;                                           // s_endpgm waits for what is still in flight
+  }
 #define GN_TS(role, b, k) do { if (a.ts && lane == 0 && (b) >= 8 && (b) < 12) a.ts[((role) * 4 + (b) - 8) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   // block table -> LDS; every role calls this AFTER issuing its first fetches (one cold round trip for both)
   auto copy_table = [&]() {
@@ -505,7 +543,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
         gn_ld16(wa[s][kk][0], wd + ((kk * JU + wave) * 2 + 0) * m);
         gn_ld16(wa[s][kk][1], wd + ((kk * JU + wave) * 2 + 1) * m);
       }
-      const f32x4* u0 = real ? reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * gridDim.x + tile) * (JU * 4) + wave * 4) * 64 + ulane
+      const f32x4* u0 = real ? reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * a.ntiles + tile) * (JU * 4) + wave * 4) * 64 + ulane
                              : reinterpret_cast<const f32x4*>(a.params);
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) gn_ld16(u0q[s][rq], u0 + rq * m);
@@ -800,7 +838,8 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
         for (int rq = 0; rq < 4; ++rq) {
           const f32x4 bv = *reinterpret_cast<const f32x4*>(bsp + 8 * rq);
           *reinterpret_cast<f32x4*>(dst + 8 * rq) =
-              f32x4{acc[4 * rq + 0] + bv.x, acc[4 * rq + 1] + bv.y, acc[4 * rq + 2] + bv.z, acc[4 * rq + 3] + bv.w};
+              f32x4{wn_act(acc[4 * rq + 0] + bv.x, a.skip_act), wn_act(acc[4 * rq + 1] + bv.y, a.skip_act),
+                    wn_act(acc[4 * rq + 2] + bv.z, a.skip_act), wn_act(acc[4 * rq + 3] + bv.w, a.skip_act)};
         }
       };
       put(acc0, t0);
@@ -950,7 +989,10 @@ static void gn_launch(const WnGenStepArgs& a, hipStream_t s) {
   if (wn_debug_get(23) != 1 && a.nblocks <= WN_GEN_CHAIN_MAX_BLOCKS) {
     WnGenStepArgs a2 = a;
     a2.ts = wn_debug_get(24) ? wn_gen_ts_buffer() : nullptr;
-    hipLaunchKernelGGL((wn_gen_chain3_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + R32 + (a.skip_tiles + 1) / 2)), 0, s, a2);
+    a2.ntiles = (int)gx;
+    // knob 25 = 1: no helper workgroups
+    const unsigned helpers = wn_debug_get(25) == 1 ? 0u : 8u * WN_GEN_HELPERS_PER_XCD;
+    hipLaunchKernelGGL((wn_gen_chain3_kernel<R32, D32, KS>), dim3(gx + helpers), dim3(64 * (2 * D32 + R32 + (a.skip_tiles + 1) / 2)), 0, s, a2);
   }
   else
     hipLaunchKernelGGL((wn_gen_chain_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + a.skip_tiles)), 0, s, a);

@@ -191,11 +191,12 @@ struct WnGenStepArgs {
   int64_t skip_bias_off;           // summed skip biases
   int64_t skiprow_off;             // [B][skip_ld] folded skip sum of this step
   int32_t skip_tiles, skip_ld;     // skip waves (column tiles of 32) carried by the chain kernel, or 0
+  int32_t skip_act, pad1_;         // activation of the folded skip sum (the head's first conv when the plan folds it in)
   int64_t u0_off;                  // [N][tiles][2D/32 * 1024] partial gated-conv accumulators (pre kernel -> chain)
   int64_t tau;
   int32_t B, nblocks, residual;
-  int32_t pad_;
-  unsigned long long* ts;          // TIMING EXPERIMENT
+  int32_t ntiles;                  // utterance tiles = chain workgroups (the chain launch appends helper workgroups)
+  unsigned long long* ts;          // phase stamps (debug switch 24) or null
   WnGenBlock blk0[3];              // blocks[0..2] by value (the first fetches do not wait for the table)
 };
 // the head of a generation step in one launch (wn_gen.hip)

@@ -1307,7 +1307,9 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = wn_launch_vecsum(v, s);
     if (rc) return rc;
   }
-  const bool fold = training && !rings && fold_ok(p);
+  // (inference and the generation priming pass fold too: the queued sampler carries the folded contraction in its chain
+  // kernel and must reproduce the sliding window bit for bit)
+  const bool fold = fold_ok(p);
   if (fold && prep) {
     const BlockInfo& b0 = p->blocks[0];
     const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
@@ -2360,7 +2362,12 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
                       (int64_t)p->N * B * p->D < (1LL << 31);
   const bool fused_step = p->fused16_ok && p->LPB == 1 && wn_debug_get(1) != 1 && wn_debug_get(6) != 1 && fits32 &&
                           wn_gen_blocks_supported(p->R, p->D, p->KS);
-  const bool skip_in_chain = fused_step && p->c.use_skip && p->frag16_skipF >= 0 && wn_gen_skip_fusable(p->Sh) &&
+  // the folded form (skip sum and the head's first conv as one contraction, as in forward_core): half the columns
+  const bool gfold = fold_ok(p);
+  const int skipw = gfold ? p->fold_F0 : p->Sh;
+  const int64_t skip_img = gfold ? p->frag16_foldF : p->frag16_skipF;
+  const size_t first_final = gfold ? 1 : 0;
+  const bool skip_in_chain = fused_step && p->c.use_skip && skip_img >= 0 && wn_gen_skip_fusable(skipw) &&
                              wn_debug_get(6) != 2;   // knob 6 = 2: skip contraction as its own launch
   if (fused_step && (!p->d_gen || p->gen_B != B)) {
     std::vector<WnGenBlock> tab(p->N);
@@ -2393,9 +2400,10 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       ga.u0_off = G.u0;
       for (int b = 0; b < 3; ++b) ga.blk0[b] = p->gen_blk0[b];
       if (skip_in_chain) {
-        ga.skip_w16_off = G.prime + L.frag + p->frag16_skipF;
-        ga.skip_bias_off = G.prime + L.bias_sum;
-        ga.skiprow_off = G.skiprow; ga.skip_ld = p->Sh; ga.skip_tiles = p->Sh / 32;
+        ga.skip_w16_off = G.prime + L.frag + skip_img;
+        ga.skip_bias_off = G.prime + (gfold ? L.bfold : L.bias_sum);
+        ga.skiprow_off = G.skiprow; ga.skip_ld = skipw; ga.skip_tiles = skipw / 32;
+        ga.skip_act = gfold ? p->c.activation : WN_ACT_LINEAR;
       }
       ga.zrow_off = G.Zrow; ga.hrow_off = p->c.use_skip ? -1 : G.hrow0; ga.tau = tau;
       ga.B = B; ga.nblocks = p->N; ga.residual = p->c.use_residual;
@@ -2455,36 +2463,40 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       hin = workspace + G.skiprow;
     } else if (p->c.use_skip) {
       // utterances are the ROWS of these contractions (no time shift, no per-utterance bias here)
-      rc = Gemm(1, B, p->Sh, ceil32(p->Sh)).seg_planes(Zrow, p->Dp, (int64_t)B * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
-               .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
-               .bias(pws + L.bias_sum).run(workspace + G.skiprow, p->Sh, s);
+      rc = Gemm(1, B, skipw, ceil32(skipw)).seg_planes(Zrow, p->Dp, (int64_t)B * p->Dp, p->N * p->Dp, gfold ? nullptr : fragbase + p->frag_skipF)
+               .w16(skip_img >= 0 ? fragbase + skip_img : nullptr)
+               .bias(pws + (gfold ? L.bfold : L.bias_sum)).act(gfold ? p->c.activation : WN_ACT_LINEAR)
+               .run(workspace + G.skiprow, skipw, s);
       if (rc) return rc;
       hin = workspace + G.skiprow;
     } else {
       hin = workspace + G.hrow0;
     }
-    int hc = p->Hin;
+    int hc = (gfold && p->c.use_skip) ? skipw : p->Hin;
     // the whole head in one launch when every layer is one the split-precision rows GEMM would take
     // (knob 6 = 4: one launch per layer)
-    bool head_fused = fused_step && wn_debug_get(6) != 4 && !p->finals.empty() && (int)p->finals.size() <= WN_GEN_HEAD_MAX &&
-                      p->Hin % 16 == 0 && p->Hin <= 256;
-    for (const ConvInfo& c : p->finals)
+    bool head_fused = fused_step && wn_debug_get(6) != 4 && p->finals.size() > first_final &&
+                      (int)(p->finals.size() - first_final) <= WN_GEN_HEAD_MAX && hc % 16 == 0 && hc <= 256;
+    for (size_t i = first_final; i < p->finals.size(); ++i) {
+      const ConvInfo& c = p->finals[i];
       head_fused = head_fused && c.frag16 >= 0 && c.cout % 32 == 0 && c.cout >= 64 && c.cout <= 256 && c.cin % 16 == 0 && c.cin <= 256;
+    }
     if (head_fused) {
       WnGenHeadArgs ha;
       memset(&ha, 0, sizeof(ha));
-      ha.params = params; ha.ws = workspace; ha.in_off = hin - workspace; ha.in_ld = p->Hin; ha.out_off = G.last;
-      ha.nlayers = (int)p->finals.size(); ha.B = B;
-      for (size_t i = 0; i < p->finals.size(); ++i) {
+      ha.params = params; ha.ws = workspace; ha.in_off = hin - workspace; ha.in_ld = hc; ha.out_off = G.last;
+      ha.nlayers = (int)(p->finals.size() - first_final); ha.B = B;
+      for (size_t i = first_final; i < p->finals.size(); ++i) {
         const ConvInfo& c = p->finals[i];
-        ha.w16_off[i] = G.prime + L.frag + c.frag16; ha.bias_off[i] = p->tensors[c.bias_t].off;
-        ha.K[i] = c.cin; ha.N[i] = c.cout;
-        ha.act[i] = (i + 1 == p->finals.size()) ? WN_ACT_LINEAR : p->c.activation;
+        const size_t l = i - first_final;
+        ha.w16_off[l] = G.prime + L.frag + c.frag16; ha.bias_off[l] = p->tensors[c.bias_t].off;
+        ha.K[l] = c.cin; ha.N[l] = c.cout;
+        ha.act[l] = (i + 1 == p->finals.size()) ? WN_ACT_LINEAR : p->c.activation;
       }
       rc = wn_launch_gen_head(ha, s);
       if (rc) return rc;
     } else {
-    for (size_t i = 0; i < p->finals.size(); ++i) {
+    for (size_t i = first_final; i < p->finals.size(); ++i) {
       const ConvInfo& c = p->finals[i];
       const bool lastl = (i + 1 == p->finals.size());
       float* dst = lastl ? last : workspace + G.HArow[i];
