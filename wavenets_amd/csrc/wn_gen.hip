@@ -426,6 +426,27 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
 // idle), the conv1 waves in phase A, the skip waves in phases A and B.  LDS only holds the exchange
 // buffers (u tiles, x operands, 2 x z operands) and a copy of the block table.
 #define WN_GEN_CHAIN_MAX_BLOCKS 128
+// acc += W^T b over NK k-steps (hi|lo B operands in LDS, 2 KB a k-step), the three products of a k-step in the order of
+// the training kernels.  The operands of k-step k + 1 are requested BEFORE the products of k-step k are issued: written
+// the plain way the compiler reads, waits, multiplies, reads, ... and every k-step pays an LDS round trip (measured on
+// the conv1 waves: 1220 -> 550 cycles for the 12 products).
+template <int NK>
+__device__ __forceinline__ void gn_mac(f32x16& acc, const gn_h8 (&w)[NK][2], const gn_h8* zl) {
+  gn_h8 bh[2], bl[2];
+  bh[0] = zl[0];
+  bl[0] = zl[64];
+  wn_static_for<NK>([&](auto kc) {
+    constexpr int ks = decltype(kc)::value;
+    if constexpr (ks + 1 < NK) {
+      bh[(ks + 1) & 1] = zl[((ks + 1) * 2 + 0) * 64];
+      bl[(ks + 1) & 1] = zl[((ks + 1) * 2 + 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);            // keep the two reads above the products below
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][1], bh[ks & 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][0], bl[ks & 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][0], bh[ks & 1], acc, 0, 0, 0);
+  });
+}
 #define WN_GEN_HELPERS_PER_XCD 2
 // The prefetches are issued as inline asm and waited for by hand: the compiler's own s_waitcnt placement drains vmcnt to 0
 // at every use inside a loop, which would cut the distance of a 3-blocks-ahead fetch to one block.  vmcnt retires in
@@ -582,15 +603,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
           for (int rq = 0; rq < 4; ++rq) {
             u[4 * rq + 0] = u0q[s][rq].x; u[4 * rq + 1] = u0q[s][rq].y; u[4 * rq + 2] = u0q[s][rq].z; u[4 * rq + 3] = u0q[s][rq].w;
           }
-          const gn_h8* xl = reinterpret_cast<const gn_h8*>(xop) + lane;
-          wn_static_for<KSR>([&](auto kc) {
-            constexpr int kk = decltype(kc)::value;
-            const gn_h8 bh = xl[(kk * 2 + 0) * 64];
-            const gn_h8 bl = xl[(kk * 2 + 1) * 64];
-            u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s][kk][1], bh, u, 0, 0, 0);
-            u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s][kk][0], bl, u, 0, 0, 0);
-            u = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s][kk][0], bh, u, 0, 0, 0);
-          });
+          gn_mac<KSR>(u, wa[s], reinterpret_cast<const gn_h8*>(xop) + lane);
           f32x4* ub = reinterpret_cast<f32x4*>(ubuf) + (wave * 4) * 64 + lane;
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
@@ -704,15 +717,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
           for (int rq = 0; rq < 4; ++rq) {
             o[4 * rq + 0] = bq[s][rq].x; o[4 * rq + 1] = bq[s][rq].y; o[4 * rq + 2] = bq[s][rq].z; o[4 * rq + 3] = bq[s][rq].w;
           }
-          const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop + (b & 1) * ZOP_BYTES) + lane;
-          wn_static_for<KS2>([&](auto kc) {
-            constexpr int ks = decltype(kc)::value;
-            const gn_h8 bh = zl[(ks * 2 + 0) * 64];
-            const gn_h8 bl = zl[(ks * 2 + 1) * 64];
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[s][ks][1], bh, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[s][ks][0], bl, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[s][ks][0], bh, o, 0, 0, 0);
-          });
+          gn_mac<KS2>(o, wc[s], reinterpret_cast<const gn_h8*>(zop + (b & 1) * ZOP_BYTES) + lane);
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = a.residual ? o[r] + x[r] : o[r];
           if (b + 1 < nblocks) put_xop(x, cw);
@@ -760,15 +765,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       for (int ks = 0; ks < KS2; ++ks) { gn_landed(w[ks][0]); gn_landed(w[ks][1]); }
     };
     auto mac = [&](f32x16& acc, const gn_h8 (&w)[KS2][2], int half) {
-      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop + half * ZOP_BYTES) + lane;
-#pragma unroll
-      for (int ks = 0; ks < KS2; ++ks) {
-        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
-        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][1], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][0], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][0], bh, acc, 0, 0, 0);
-      }
+      gn_mac<KS2>(acc, w, reinterpret_cast<const gn_h8*>(zop + half * ZOP_BYTES) + lane);
     };
     f32x16 acc0, acc1;
 #pragma unroll
