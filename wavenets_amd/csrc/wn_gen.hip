@@ -47,12 +47,11 @@ struct GnShape {
 };
 
 template <int R32, int D32, int KS>
-__global__ __launch_bounds__(64) void wn_gen_pre_kernel(WnGenStepArgs a) {
+__device__ __forceinline__ void gn_pre_body(const WnGenStepArgs& a, int tile, int b, int ntiles) {
   using S = GnShape<R32, D32, KS>;
   constexpr int R = S::R, D = S::D, JU = S::JU, QR = S::QR, KSR = S::KSR, KS0 = S::KS0;
   const int lane = threadIdx.x & 63;
   const int tl = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x, b = blockIdx.y;
   const int utt = tile * 32 + tl;
   const int ur = utt < a.B ? utt : 0;
   const WnGenBlock blk = a.blocks[b];
@@ -108,12 +107,16 @@ __global__ __launch_bounds__(64) void wn_gen_pre_kernel(WnGenStepArgs a) {
     }
   });
   // lane-major image [b][tile][JU * 4 quads][64 lanes] of float4: contiguous KiB per quad (LDS-DMA friendly)
-  f32x4* dst = reinterpret_cast<f32x4*>(a.ws + a.u0_off) + ((int64_t)b * gridDim.x + tile) * (JU * 4) * 64 + lane;
+  f32x4* dst = reinterpret_cast<f32x4*>(a.ws + a.u0_off) + ((int64_t)b * ntiles + tile) * (JU * 4) * 64 + lane;
 #pragma unroll
   for (int j = 0; j < JU; ++j)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq)
       dst[(j * 4 + rq) * 64] = f32x4{u[j][4 * rq + 0], u[j][4 * rq + 1], u[j][4 * rq + 2], u[j][4 * rq + 3]};
+}
+template <int R32, int D32, int KS>
+__global__ __launch_bounds__(64) void wn_gen_pre_kernel(WnGenStepArgs a) {
+  gn_pre_body<R32, D32, KS>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 // workgroup barrier that only drains this wave's LDS/SMEM traffic: __syncthreads() would also wait for
@@ -852,11 +855,10 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
 // the next layer through LDS, exactly as the chain kernel hands x between blocks.  Per tile this is the
 // thin rows GEMM's sequence -- k-steps in order, lo*hi, hi*lo, hi*hi, then acc + bias, activation -- so
 // the logits are bit-identical to the per-layer launches (and to the sliding window).
-__global__ __launch_bounds__(512) void wn_gen_head_kernel(WnGenHeadArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16 * 2048];       // two operand buffers of 16 k-steps
+__device__ __forceinline__ void gn_head_body(const WnGenHeadArgs& a, int tile, unsigned char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tl = lane & 31, h = lane >> 5;
-  const int utt = blockIdx.x * 32 + tl;
+  const int utt = tile * 32 + tl;
   const bool live = utt < a.B;
   const int ur = live ? utt : 0;
   // ---- input rows -> operand buffer 0: wave w converts k-steps w, w + 8 ----
@@ -943,6 +945,46 @@ __global__ __launch_bounds__(512) void wn_gen_head_kernel(WnGenHeadArgs a) {
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(512) void wn_gen_head_kernel(WnGenHeadArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16 * 2048];       // two operand buffers of 16 k-steps
+  gn_head_body(a, (int)blockIdx.x, smem);
+}
+// The head of step tau and, in further workgroups of the same launch, the pre kernel's work for step tau + 1: that part
+// reads rings only, all written once the chain kernel of step tau has finished, so it does not have to wait for the
+// sample -- one launch (and its gap) less per step.
+template <int R32, int D32, int KS>
+__global__ __launch_bounds__(512) void wn_gen_head_pre_kernel(WnGenHeadArgs ha, WnGenStepArgs ga, int ntiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16 * 2048];
+  if ((int)blockIdx.x < ntiles) {
+    gn_head_body(ha, (int)blockIdx.x, smem);
+  } else {
+    if (threadIdx.x >= 64) return;                    // one wave per (tile, block), as in the stand-alone launch
+    const int j = (int)blockIdx.x - ntiles;
+    gn_pre_body<R32, D32, KS>(ga, j % ntiles, j / ntiles, ntiles);
+  }
+}
+
+static int gn_head_check(const WnGenHeadArgs& a) {
+  if (a.nlayers < 1 || a.nlayers > WN_GEN_HEAD_MAX) { wn_set_error("gen_head: bad layer count"); return WN_E_UNSUPPORTED; }
+  for (int i = 0; i < a.nlayers; ++i)
+    if (a.K[i] % 16 != 0 || a.K[i] > 256 || a.N[i] % 32 != 0 || a.N[i] > 256 || (i > 0 && a.K[i] != a.N[i - 1])) {
+      wn_set_error("gen_head: unsupported layer shape");
+      return WN_E_UNSUPPORTED;
+    }
+  return WN_OK;
+}
+int wn_launch_gen_head_pre(const WnGenHeadArgs& a, const WnGenStepArgs& g, int R, int KS, hipStream_t s) {
+  const int rc = gn_head_check(a);
+  if (rc) return rc;
+  const int nt = (a.B + 31) / 32;
+  const dim3 grid((unsigned)(nt + nt * g.nblocks));
+  if (R == 32 && KS == 2) hipLaunchKernelGGL((wn_gen_head_pre_kernel<1, 1, 2>), grid, dim3(512), 0, s, a, g, nt);
+  else if (R == 32 && KS == 3) hipLaunchKernelGGL((wn_gen_head_pre_kernel<1, 1, 3>), grid, dim3(512), 0, s, a, g, nt);
+  else if (R == 64 && KS == 2) hipLaunchKernelGGL((wn_gen_head_pre_kernel<2, 2, 2>), grid, dim3(512), 0, s, a, g, nt);
+  else { wn_set_error("gen_head_pre: unsupported shape"); return WN_E_UNSUPPORTED; }
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
 
 int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s) {
   if (a.nlayers < 1 || a.nlayers > WN_GEN_HEAD_MAX) { wn_set_error("gen_head: bad layer count"); return WN_E_UNSUPPORTED; }
@@ -979,9 +1021,10 @@ extern "C" int wn_debug_gen_ts(unsigned long long* out) {
   return (int)hipMemcpy(out, g_gen_ts, 3 * 4 * 8 * 8, hipMemcpyDeviceToHost);
 }
 template <int R32, int D32, int KS>
-static void gn_launch(const WnGenStepArgs& a, hipStream_t s) {
+static void gn_launch(const WnGenStepArgs& a, int what, hipStream_t s) {   // what: 1 pre, 2 chain, 3 both
   const unsigned gx = (unsigned)((a.B + 31) / 32);
-  hipLaunchKernelGGL((wn_gen_pre_kernel<R32, D32, KS>), dim3(gx, (unsigned)a.nblocks), dim3(64), 0, s, a);
+  if (what & 1) hipLaunchKernelGGL((wn_gen_pre_kernel<R32, D32, KS>), dim3(gx, (unsigned)a.nblocks), dim3(64), 0, s, a);
+  if (!(what & 2)) return;
   // knob 23 = 1 or a very deep stack: the first form (weights through an LDS image filled by LDS-DMA)
   if (wn_debug_get(23) != 1 && a.nblocks <= WN_GEN_CHAIN_MAX_BLOCKS) {
     WnGenStepArgs a2 = a;
@@ -995,10 +1038,12 @@ static void gn_launch(const WnGenStepArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((wn_gen_chain_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + a.skip_tiles)), 0, s, a);
 }
 
-int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, hipStream_t s) {
-  if (R == 32 && KS == 2) gn_launch<1, 1, 2>(a, s);
-  else if (R == 32 && KS == 3) gn_launch<1, 1, 3>(a, s);
-  else if (R == 64 && KS == 2) gn_launch<2, 2, 2>(a, s);
+// what: 1 = the pre kernel (older taps of every block for time a.tau: reads rings only, so it may run as soon as the
+// chain kernel of time a.tau - 1 has finished), 2 = the chain kernel, 3 = both in order
+int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, int what, hipStream_t s) {
+  if (R == 32 && KS == 2) gn_launch<1, 1, 2>(a, what, s);
+  else if (R == 32 && KS == 3) gn_launch<1, 1, 3>(a, what, s);
+  else if (R == 64 && KS == 2) gn_launch<2, 2, 2>(a, what, s);
   else { wn_set_error("gen_blocks: unsupported shape"); return WN_E_UNSUPPORTED; }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;

@@ -215,7 +215,8 @@ int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s);
 int wn_gen_blocks_supported(int R, int D, int KS);
 int64_t wn_gen_u0_floats(int B, int nblocks, int D);
 int wn_gen_skip_fusable(int S);
-int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, hipStream_t s);
+int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, int what, hipStream_t s);
+int wn_launch_gen_head_pre(const WnGenHeadArgs& a, const WnGenStepArgs& g, int R, int KS, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise / loss / sampling
 int wn_launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t s);

@@ -2389,11 +2389,22 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     p->gen_B = B;
     for (int b = 0; b < 3; ++b) p->gen_blk0[b] = tab[std::min(b, p->N - 1)];
   }
+  const int hc0 = (gfold && p->c.use_skip) ? skipw : p->Hin;
+  // the whole head in one launch when every layer is one the split-precision rows GEMM would take
+  // (knob 6 = 4: one launch per layer)
+  bool head_fused = fused_step && wn_debug_get(6) != 4 && p->finals.size() > first_final &&
+                    (int)(p->finals.size() - first_final) <= WN_GEN_HEAD_MAX && hc0 % 16 == 0 && hc0 <= 256;
+  for (size_t i = first_final; i < p->finals.size(); ++i) {
+    const ConvInfo& c = p->finals[i];
+    head_fused = head_fused && c.frag16 >= 0 && c.cout % 32 == 0 && c.cout >= 64 && c.cout <= 256 && c.cin % 16 == 0 && c.cin <= 256;
+  }
+  // the pre kernel's work of step tau + 1 rides in the head launch of step tau (knob 26 = 1: its own launch)
+  const bool pre_in_head = head_fused && wn_debug_get(26) != 1;
+  WnGenStepArgs ga;
+  memset(&ga, 0, sizeof(ga));
   for (int step = 1; step < length; ++step) {
     const int64_t tau = (int64_t)RF + step - 1;        // time of the newest known sample
     if (fused_step) {
-      WnGenStepArgs ga;
-      memset(&ga, 0, sizeof(ga));
       ga.params = params; ga.ws = workspace; ga.blocks = p->d_gen; ga.xin = R.xin;
       ga.causal_w = params + p->tensors[p->causal.kernel_t].off;
       ga.causal_b = params + p->tensors[p->causal.bias_t].off;
@@ -2407,7 +2418,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       }
       ga.zrow_off = G.Zrow; ga.hrow_off = p->c.use_skip ? -1 : G.hrow0; ga.tau = tau;
       ga.B = B; ga.nblocks = p->N; ga.residual = p->c.use_residual;
-      rc = wn_launch_gen_blocks(ga, p->R, p->KS, s);
+      rc = wn_launch_gen_blocks(ga, p->R, p->KS, (pre_in_head && step > 1) ? 2 : 3, s);
       if (rc) return rc;
     } else {
     // input causal conv on [x[tau-(KS-1)], ..., x[tau]]  ->  block 0's ring slot tau
@@ -2472,15 +2483,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     } else {
       hin = workspace + G.hrow0;
     }
-    int hc = (gfold && p->c.use_skip) ? skipw : p->Hin;
-    // the whole head in one launch when every layer is one the split-precision rows GEMM would take
-    // (knob 6 = 4: one launch per layer)
-    bool head_fused = fused_step && wn_debug_get(6) != 4 && p->finals.size() > first_final &&
-                      (int)(p->finals.size() - first_final) <= WN_GEN_HEAD_MAX && hc % 16 == 0 && hc <= 256;
-    for (size_t i = first_final; i < p->finals.size(); ++i) {
-      const ConvInfo& c = p->finals[i];
-      head_fused = head_fused && c.frag16 >= 0 && c.cout % 32 == 0 && c.cout >= 64 && c.cout <= 256 && c.cin % 16 == 0 && c.cin <= 256;
-    }
+    int hc = hc0;
     if (head_fused) {
       WnGenHeadArgs ha;
       memset(&ha, 0, sizeof(ha));
@@ -2493,7 +2496,13 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
         ha.K[l] = c.cin; ha.N[l] = c.cout;
         ha.act[l] = (i + 1 == p->finals.size()) ? WN_ACT_LINEAR : p->c.activation;
       }
-      rc = wn_launch_gen_head(ha, s);
+      if (pre_in_head && step + 1 < length) {
+        WnGenStepArgs gn = ga;
+        gn.tau = tau + 1;
+        rc = wn_launch_gen_head_pre(ha, gn, p->R, p->KS, s);
+      } else {
+        rc = wn_launch_gen_head(ha, s);
+      }
       if (rc) return rc;
     } else {
     for (size_t i = first_final; i < p->finals.size(); ++i) {
