@@ -10,11 +10,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device('cuda', 0)
 m = WaveNet(**bench.CFG2, device=dev)
 w = (torch.rand(B, m.receptive_field, 1, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
-for name, queued, n in (('naive', False, 20), ('queued', True, 400)):
-  m.generate(3, sample=w, use_queues=queued, deterministic=True)
+for name, queued, n, det in (('naive', False, 20, True), ('queued', True, 400, True), ('queued, stochastic draws', True, 400, False)):
+  m.generate(3, sample=w, use_queues=queued, deterministic=det)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
-  out = m.generate(n, sample=w, use_queues=queued, deterministic=True)
+  out = m.generate(n, sample=w, use_queues=queued, deterministic=det)
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   print(f'{name}: B={B} {n} samples/utterance in {dt:.3f} s -> {n / dt:.1f} samples/s per utterance, '

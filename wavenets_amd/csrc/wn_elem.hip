@@ -510,6 +510,13 @@ int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scr
 
 // ------------------------------------------------------------------------------------------
 // samplers
+// (queued generation: the sample also goes to its place in the output rows and into the network's input ring -- the
+// emit step of a generation step rides in the sampler's launch)
+__device__ __forceinline__ void wn_emit_sample(const WnEmit& e, int64_t row, float v) {
+  if (!e.out) return;
+  e.out[row * e.length + e.step] = v;
+  if (e.xin_slot) e.xin_slot[row] = v;
+}
 __global__ __launch_bounds__(256) void wn_sample_det_cat_kernel(const float* pred, int64_t rows, int C,
                                                                 float inv, float* out) {
   const int lane = threadIdx.x & 63;
@@ -530,24 +537,31 @@ __global__ __launch_bounds__(256) void wn_sample_det_cat_kernel(const float* pre
   }
   if (lane == 0) out[row] = (float)bi * inv - 1.0f;
 }
-__global__ void wn_sample_det_mix_kernel(const float* pred, int64_t rows, int M, float* out) {
+__global__ void wn_sample_det_mix_kernel(const float* pred, int64_t rows, int M, float* out, WnEmit em) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   const float* p = pred + row * 3 * M;
   int bi = 0;
   float best = p[0];
   for (int k = 1; k < M; ++k) if (p[k] > best) { best = p[k]; bi = k; }
-  out[row] = fminf(fmaxf(p[M + bi], -1.0f), 1.0f);
+  const float v = fminf(fmaxf(p[M + bi], -1.0f), 1.0f);
+  out[row] = v;
+  wn_emit_sample(em, row, v);
 }
 int wn_launch_sample_det(const float* pred, int64_t rows, int C, int M, int bits, float* out,
                          hipStream_t s) {
+  return wn_launch_sample_det_emit(pred, rows, C, M, bits, out, WnEmit{nullptr, 0, 0, nullptr}, s);
+}
+// (categorical rows with an emit target go through wn_launch_gen_tail_cat_det, which starts from the logits)
+int wn_launch_sample_det_emit(const float* pred, int64_t rows, int C, int M, int bits, float* out, WnEmit em, hipStream_t s) {
   if (rows <= 0) return WN_OK;
+  if (M <= 0 && em.out) { wn_set_error("sample_det_emit: categorical rows use the fused tail"); return WN_E_INVALID; }
   if (M <= 0) {
     hipLaunchKernelGGL(wn_sample_det_cat_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                        pred, rows, C, 1.0f / (float)(1 << (bits - 1)), out);
   } else {
     hipLaunchKernelGGL(wn_sample_det_mix_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       s, pred, rows, M, out);
+                       s, pred, rows, M, out, em);
   }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(256) void wn_sample_rand_cat_kernel(const float* pr
 #define WN_SAMPLE_FUSED_MAXC 1024
 __global__ __launch_bounds__(256) void wn_sample_rand_cat_logits_kernel(const float* logits, int64_t rows, int C,
                                                                         float inv_lv, uint64_t seed, uint64_t offset,
-                                                                        float* out) {
+                                                                        float* out, WnEmit em) {
   __shared__ float q[4][WN_SAMPLE_FUSED_MAXC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + w;
@@ -608,20 +622,28 @@ __global__ __launch_bounds__(256) void wn_sample_rand_cat_logits_kernel(const fl
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int result = wn_draw_cat_row((const float*)q[w], C, lane, row, seed, offset);
-  if (lane == 0) out[row] = (float)result * inv_lv - 1.0f;
+  if (lane == 0) {
+    const float v = (float)result * inv_lv - 1.0f;
+    out[row] = v;
+    wn_emit_sample(em, row, v);
+  }
 }
 int wn_sample_from_logits_supported(int C) { return C <= WN_SAMPLE_FUSED_MAXC ? 1 : 0; }
 int wn_launch_sample_rand_cat_logits(const float* logits, int64_t rows, int C, int bits, uint64_t seed, uint64_t offset,
                                      float* out, hipStream_t s) {
+  return wn_launch_sample_rand_cat_logits_emit(logits, rows, C, bits, seed, offset, out, WnEmit{nullptr, 0, 0, nullptr}, s);
+}
+int wn_launch_sample_rand_cat_logits_emit(const float* logits, int64_t rows, int C, int bits, uint64_t seed, uint64_t offset,
+                                          float* out, WnEmit em, hipStream_t s) {
   if (rows <= 0) return WN_OK;
   if (C > WN_SAMPLE_FUSED_MAXC) { wn_set_error("sample from logits: %d classes > %d", C, WN_SAMPLE_FUSED_MAXC); return WN_E_UNSUPPORTED; }
   hipLaunchKernelGGL(wn_sample_rand_cat_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, rows, C,
-                     1.0f / (float)(1 << (bits - 1)), seed, offset, out);
+                     1.0f / (float)(1 << (bits - 1)), seed, offset, out, em);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
 __global__ void wn_sample_rand_mix_kernel(const float* pred, int64_t rows, int M, int kind, uint64_t seed,
-                                          uint64_t offset, float* out) {
+                                          uint64_t offset, float* out, WnEmit em) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   const float* p = pred + row * 3 * M;
@@ -644,17 +666,25 @@ __global__ void wn_sample_rand_mix_kernel(const float* pred, int64_t rows, int M
     const float u1 = wn_u01(r[1]), u2 = wn_u01(r[2]);
     v = mu + sc * sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
   }
-  out[row] = fminf(fmaxf(v, -1.0f), 1.0f);
+  const float vc = fminf(fmaxf(v, -1.0f), 1.0f);
+  out[row] = vc;
+  wn_emit_sample(em, row, vc);
 }
 int wn_launch_sample_rand(const float* pred, int64_t rows, int C, int M, int bits, int kind,
                           uint64_t seed, uint64_t offset, float* out, hipStream_t s) {
+  return wn_launch_sample_rand_emit(pred, rows, C, M, bits, kind, seed, offset, out, WnEmit{nullptr, 0, 0, nullptr}, s);
+}
+// (categorical rows with an emit target go through wn_launch_sample_rand_cat_logits_emit)
+int wn_launch_sample_rand_emit(const float* pred, int64_t rows, int C, int M, int bits, int kind,
+                               uint64_t seed, uint64_t offset, float* out, WnEmit em, hipStream_t s) {
   if (rows <= 0) return WN_OK;
+  if (M <= 0 && em.out) { wn_set_error("sample_rand_emit: categorical rows start from the logits"); return WN_E_INVALID; }
   if (M <= 0) {
     hipLaunchKernelGGL(wn_sample_rand_cat_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                        pred, rows, C, 1.0f / (float)(1 << (bits - 1)), seed, offset, out);
   } else {
     hipLaunchKernelGGL(wn_sample_rand_mix_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       s, pred, rows, M, kind, seed, offset, out);
+                       s, pred, rows, M, kind, seed, offset, out, em);
   }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;

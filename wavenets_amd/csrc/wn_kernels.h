@@ -275,6 +275,13 @@ int wn_launch_mix_loss(const float* pred, const float* y, int64_t rows, int M, i
                        float gscale, float* loss_rows, float* g_pred, float* absmax_out, hipStream_t s);
 int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scratch, hipStream_t s);
 // deterministic samplers: categorical argmax -> left bin edge; mixtures -> clipped mean
+// queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)
+struct WnEmit { float* out; int length; int step; float* xin_slot; };
+int wn_launch_sample_det_emit(const float* pred, int64_t rows, int C, int M, int bits, float* out, WnEmit em, hipStream_t s);
+int wn_launch_sample_rand_emit(const float* pred, int64_t rows, int C, int M, int bits, int kind, uint64_t seed, uint64_t offset,
+                               float* out, WnEmit em, hipStream_t s);
+int wn_launch_sample_rand_cat_logits_emit(const float* logits, int64_t rows, int C, int bits, uint64_t seed, uint64_t offset,
+                                          float* out, WnEmit em, hipStream_t s);
 int wn_launch_sample_det(const float* pred, int64_t rows, int C, int M, int bits, float* out,
                          hipStream_t s);
 // stochastic samplers (Philox4x32-10 keyed by seed, counter = row)

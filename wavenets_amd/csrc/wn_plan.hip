@@ -2521,11 +2521,23 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       rc = wn_launch_gen_tail_cat_det(last, B, p->Cout, p->c.bits, out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B, s);
       if (rc) return rc;
     } else {
-      rc = sample_rows(p, last, B, deterministic != 0, seed, (uint64_t)step, lastp, samp, s);
-      if (rc) return rc;
-      hipLaunchKernelGGL(wn_gen_emit_kernel, dim3((B + 255) / 256), dim3(256), 0, s, samp, B, out, length, step,
-                         R.xin + (int64_t)((tau + 1) % p->KS) * B);
-      WN_HIP_CHECK(hipGetLastError());
+      // sampler and emit in one launch (categorical draws straight from the logits: the softmax of
+      // wn_softmax_kernel in LDS, the class sample_waveform(softmax(logits)) draws)
+      const WnEmit em{out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B};
+      if (p->c.head == WN_HEAD_CATEGORICAL && !deterministic && wn_sample_from_logits_supported(p->Cout) && wn_debug_get(6) != 3) {
+        rc = wn_launch_sample_rand_cat_logits_emit(last, B, p->Cout, p->c.bits, seed, (uint64_t)step, samp, em, s);
+        if (rc) return rc;
+      } else if (p->c.head != WN_HEAD_CATEGORICAL && wn_debug_get(6) != 3) {
+        if (deterministic) rc = wn_launch_sample_det_emit(last, B, p->Cout, p->c.num_mixtures, p->c.bits, samp, em, s);
+        else rc = wn_launch_sample_rand_emit(last, B, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, seed, (uint64_t)step, samp, em, s);
+        if (rc) return rc;
+      } else {
+        rc = sample_rows(p, last, B, deterministic != 0, seed, (uint64_t)step, lastp, samp, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wn_gen_emit_kernel, dim3((B + 255) / 256), dim3(256), 0, s, samp, B, out, length, step,
+                           R.xin + (int64_t)((tau + 1) % p->KS) * B);
+        WN_HIP_CHECK(hipGetLastError());
+      }
     }
   }
   return WN_OK;
