@@ -21,6 +21,7 @@
 #include <hip/hip_fp16.h>
 
 #include "wn_kernels.h"
+#include "wn_sample.h"
 
 typedef _Float16 gn_h8 __attribute__((ext_vector_type(8)));
 
@@ -943,6 +944,26 @@ __device__ __forceinline__ void gn_head_body(const WnGenHeadArgs& a, int tile, u
       }
     }
     __syncthreads();
+  }
+  // ---- categorical sampling tail (softmax -> arg max, or softmax -> inverse-CDF draw) and emit, one wave per row: the
+  // rows of wn_gen_tail_cat_det_kernel / wn_sample_rand_cat_logits_kernel, so the samples are theirs.  The logits were
+  // stored by other waves of this workgroup: the barrier above has drained those stores, and nothing has read these
+  // lines into this CU's L1 before ----
+  if (a.tail != 0) {
+    const int C = a.N[a.nlayers - 1];
+    float* q = reinterpret_cast<float*>(smem) + wave * 256;     // the operand buffers are free now (C <= 256)
+    for (int i = wave; i < 32; i += 8) {
+      const int row = tile * 32 + i;
+      if (row >= a.B) break;                          // wave-uniform
+      const float* l = a.ws + a.out_off + (int64_t)row * C;
+      const float v = a.tail == 1 ? wn_cat_det_row(l, C, lane, a.inv_lv)
+                                  : wn_cat_rand_row(l, C, lane, q, row, a.seed, a.offset, a.inv_lv);
+      if (lane == 0) {
+        if (a.samp) a.samp[row] = v;
+        a.em.out[(int64_t)row * a.em.length + a.em.step] = v;
+        if (a.em.xin_slot) a.em.xin_slot[row] = v;
+      }
+    }
   }
 }
 __global__ __launch_bounds__(512) void wn_gen_head_kernel(WnGenHeadArgs a) {

@@ -199,6 +199,8 @@ struct WnGenStepArgs {
   unsigned long long* ts;          // phase stamps (debug switch 24) or null
   WnGenBlock blk0[3];              // blocks[0..2] by value (the first fetches do not wait for the table)
 };
+// queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)
+struct WnEmit { float* out; int length; int step; float* xin_slot; };
 // the head of a generation step in one launch (wn_gen.hip)
 #define WN_GEN_HEAD_MAX 4
 struct WnGenHeadArgs {
@@ -209,7 +211,13 @@ struct WnGenHeadArgs {
   int64_t w16_off[WN_GEN_HEAD_MAX];   // fp16 split images A[N][K] (workspace offsets)
   int64_t bias_off[WN_GEN_HEAD_MAX];  // parameter offsets
   int32_t K[WN_GEN_HEAD_MAX], N[WN_GEN_HEAD_MAX], act[WN_GEN_HEAD_MAX];
-  int32_t in_ld, nlayers, B, pad_;
+  int32_t in_ld, nlayers, B;
+  // categorical sampling tail in the same launch: 0 none, 1 deterministic (arg max), 2 stochastic draw
+  int32_t tail;
+  float inv_lv;                    // 2 / levels
+  uint64_t seed, offset;           // Philox key / counter word of a stochastic draw
+  float* samp;                     // [B] samples (or null)
+  WnEmit em;                       // output rows / network input slot
 };
 int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s);
 int wn_gen_blocks_supported(int R, int D, int KS);
@@ -275,8 +283,6 @@ int wn_launch_mix_loss(const float* pred, const float* y, int64_t rows, int M, i
                        float gscale, float* loss_rows, float* g_pred, float* absmax_out, hipStream_t s);
 int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scratch, hipStream_t s);
 // deterministic samplers: categorical argmax -> left bin edge; mixtures -> clipped mean
-// queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)
-struct WnEmit { float* out; int length; int step; float* xin_slot; };
 int wn_launch_sample_det_emit(const float* pred, int64_t rows, int C, int M, int bits, float* out, WnEmit em, hipStream_t s);
 int wn_launch_sample_rand_emit(const float* pred, int64_t rows, int C, int M, int bits, int kind, uint64_t seed, uint64_t offset,
                                float* out, WnEmit em, hipStream_t s);

@@ -2484,6 +2484,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       hin = workspace + G.hrow0;
     }
     int hc = hc0;
+    bool head_tail = false;
     if (head_fused) {
       WnGenHeadArgs ha;
       memset(&ha, 0, sizeof(ha));
@@ -2495,6 +2496,15 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
         ha.w16_off[l] = G.prime + L.frag + c.frag16; ha.bias_off[l] = p->tensors[c.bias_t].off;
         ha.K[l] = c.cin; ha.N[l] = c.cout;
         ha.act[l] = (i + 1 == p->finals.size()) ? WN_ACT_LINEAR : p->c.activation;
+      }
+      // categorical heads: the sampling tail and the emit ride in the head launch too (knob 6 = 3: separate kernels)
+      head_tail = p->c.head == WN_HEAD_CATEGORICAL && p->Cout <= 256 && wn_debug_get(6) != 3 && wn_debug_get(27) != 1;
+      if (head_tail) {
+        ha.tail = deterministic ? 1 : 2;
+        ha.inv_lv = 1.0f / (float)(1 << (p->c.bits - 1));
+        ha.seed = seed; ha.offset = (uint64_t)step;
+        ha.samp = samp;
+        ha.em = WnEmit{out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B};
       }
       if (pre_in_head && step + 1 < length) {
         WnGenStepArgs gn = ga;
@@ -2516,7 +2526,9 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       hin = dst; hc = c.cout;
     }
     }
-    if (p->c.head == WN_HEAD_CATEGORICAL && deterministic && wn_debug_get(6) != 3) {
+    if (head_tail) {
+      // sampled and emitted by the head launch
+    } else if (p->c.head == WN_HEAD_CATEGORICAL && deterministic && wn_debug_get(6) != 3) {
       // softmax + arg max + emit in one launch (knob 6 = 3: the three separate kernels)
       rc = wn_launch_gen_tail_cat_det(last, B, p->Cout, p->c.bits, out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B, s);
       if (rc) return rc;

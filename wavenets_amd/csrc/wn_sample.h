@@ -1,0 +1,135 @@
+// Row samplers shared by the sampling kernels (wn_elem.hip) and the generation head kernel (wn_gen.hip): one wave per row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------
+// wave-per-row helpers
+__device__ __forceinline__ float wn_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (row, offset), key = seed
+__device__ __forceinline__ void wn_philox(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key, uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float wn_u01(uint32_t r) {   // (0,1), 24-bit
+  return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// inverse-CDF categorical draw from the (unnormalised) probabilities p[0..C) of one row per wave
+// (p may live in global memory or in LDS); every lane returns the drawn class
+template <typename P>
+__device__ __forceinline__ int wn_draw_cat_row(P p, int C, int lane, int64_t row, uint64_t seed, uint64_t offset) {
+  const int per = (C + 63) / 64;               // contiguous chunk per lane
+  const int j0 = lane * per;
+  float loc = 0.f;
+  for (int j = j0; j < min(C, j0 + per); ++j) loc += fmaxf(p[j], 0.f);
+  float incl = loc;                            // inclusive scan over lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  const float total = __shfl(incl, 63);
+  uint32_t r[4];
+  wn_philox((uint64_t)row, offset, seed, r);
+  const float target = wn_u01(r[0]) * total;
+  const unsigned long long hit = __ballot(incl > target);
+  const int sel_lane = hit ? __builtin_ctzll(hit) : 63;
+  int result = C - 1;
+  if (lane == sel_lane) {
+    float run = incl - loc;
+    result = min(C, j0 + per) - 1;
+    for (int j = j0; j < min(C, j0 + per); ++j) {
+      run += fmaxf(p[j], 0.f);
+      if (run > target) { result = j; break; }
+    }
+  }
+  return __shfl(result, sel_lane);
+}
+
+
+// Categorical head, deterministic (src/model.py:393-421 with deterministic sampling): softmax -> arg max -> sample value.
+// The arithmetic is that of wn_softmax_kernel followed by wn_sample_det_cat_kernel (same lane assignment, same
+// reductions), so the result is the same sample.  Every lane returns it.
+__device__ __forceinline__ float wn_cat_det_row(const float* l, int C, int lane, float inv_lv) {
+  float m = -INFINITY;
+  for (int j = lane; j < C; j += 64) m = fmaxf(m, l[j]);
+  m = wn_wave_max(m);
+  float z = 0.f;
+  for (int j = lane; j < C; j += 64) z += expf(l[j] - m);
+  z = wn_wave_sum(z);
+  const float inv = 1.0f / z;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < C; j += 64) {
+    const float v = expf(l[j] - m) * inv;        // the probability wn_softmax_kernel would have stored
+    if (v > best) { best = v; bi = j; }          // strictly greater keeps the first maximum
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  return (float)bi * inv_lv - 1.0f;
+}
+
+// Categorical head, stochastic draw straight from the logits: the probabilities are those of wn_softmax_kernel (same lane
+// assignment, same reductions), kept in the LDS row q[0..C) instead of a (rows, C) tensor in HBM, so the drawn class is
+// the one sample_waveform(softmax(logits)) draws.  Every lane returns the sample value.
+__device__ __forceinline__ float wn_cat_rand_row(const float* l, int C, int lane, float* q, int64_t row, uint64_t seed,
+                                                 uint64_t offset, float inv_lv) {
+  if (C <= 256) {
+    // one read of the row, one exp per class (element k of a lane = class lane + 64 k: the same per-lane
+    // order of the max / sum as the loops below)
+    float v[4], e[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = lane + 64 * k < C ? l[lane + 64 * k] : -INFINITY;
+      m = fmaxf(m, v[k]);
+    }
+    m = wn_wave_max(m);
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < C) { e[k] = expf(v[k] - m); z += e[k]; }
+    z = wn_wave_sum(z);
+    const float inv = 1.0f / z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < C) q[lane + 64 * k] = e[k] * inv;
+  } else {
+    float m = -INFINITY;
+    for (int j = lane; j < C; j += 64) m = fmaxf(m, l[j]);
+    m = wn_wave_max(m);
+    float z = 0.f;
+    for (int j = lane; j < C; j += 64) z += expf(l[j] - m);
+    z = wn_wave_sum(z);
+    const float inv = 1.0f / z;
+    for (int j = lane; j < C; j += 64) q[j] = expf(l[j] - m) * inv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int result = wn_draw_cat_row((const float*)q, C, lane, row, seed, offset);
+  return (float)result * inv_lv - 1.0f;
+}
