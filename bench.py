@@ -26,6 +26,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
                   its own counter bytes.
   cpu_baseline -- the CPU oracle (restated reference, PyTorch CPU) timed on this host's cores on a bounded
                   sample of the same workload
+  generation   -- (N = 1) autoregressive generation speed on the same network, SURVEY.md 8(f)-1: queued sampler with
+                  stochastic / deterministic draws and the sliding window, per utterance and aggregate at batch 8
 """
 import argparse
 import json
@@ -56,6 +58,7 @@ def parse_args(argv=None):
   ap.add_argument('--length', type=int, default=16000, help='predicted samples per utterance')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-strong-leg', action='store_true', help='skip the extra global-batch-64 measurement')
+  ap.add_argument('--no-generation', action='store_true', help='skip the generation-speed leg (N = 1 only)')
   ap.add_argument('--cpu-budget', type=float, default=20.0)
   return ap.parse_args(argv)
 
@@ -82,6 +85,30 @@ def self_launch(args):
     raise SystemExit(res.returncode or 1)
   print(line)
   raise SystemExit(0)
+
+
+def generation_leg(dev, B: int = 8, n: int = 1000):
+  """Autoregressive generation on the configs[1] network (the reference prints 'Speed of generation was ... samples/s',
+  train.py:253-261): the queued (ring-buffer) sampler, stochastic draws as sample_waveform makes them, beside the sliding
+  window of src/model.py:296-305.  Random-init weights, a random receptive field as the seed window."""
+  import torch
+  from wavenets_amd import WaveNet
+  m = WaveNet(**CFG2, device=dev, seed=0)
+  w = (torch.rand(B, m.receptive_field, 1, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+  res = {'workload': f'configs[1] weights, batch {B}, {n} samples per utterance after a {m.receptive_field}-sample window'}
+  for name, queued, det, steps in (('queued_stochastic', True, False, n), ('queued_deterministic', True, True, n),
+                                   ('sliding_window', False, True, 20)):
+    m.generate(3, sample=w, use_queues=queued, deterministic=det)
+    ts = []
+    for k in (steps // 4, steps):                      # two lengths: the difference leaves the priming pass out
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      m.generate(k, sample=w, use_queues=queued, deterministic=det)
+      torch.cuda.synchronize()
+      ts.append(time.perf_counter() - t0)
+    per = (ts[1] - ts[0]) / (steps - steps // 4)
+    res[name] = {'ms_per_sample_step': per * 1e3, 'samples_per_s_per_utterance': 1.0 / per, 'samples_per_s_aggregate': B / per}
+  return res
 
 
 def cpu_baseline(budget_s: float = 20.0):
@@ -330,6 +357,8 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args.cpu_budget)
+    if world == 1 and not args.no_generation:
+      out['generation'] = generation_leg(dev)
     print(json.dumps(out))
   if world > 1:
     dist.barrier()

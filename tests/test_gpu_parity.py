@@ -844,6 +844,27 @@ def test_queued_generation_skip_wave_counts(skip_channels):
   assert torch.equal(naive, queued)          # continuous (mixture) outputs: equality is bit for bit
 
 
+@pytest.mark.parametrize('name,det', [('cat_r64', True), ('cat_r64', False), ('cat_small_fused', False), ('mol', False)])
+def test_queued_generation_launch_variants_agree(name, det):
+  """The queued sampler's launch variants draw the same samples as the sliding window: the first chain kernel (knob 23),
+  no L2 helper workgroups (25), the pre kernel as its own launch (26), the sampling tail as its own launch (27), softmax /
+  sampler / emit as separate kernels (6 = 3), skip contraction as its own launch (6 = 2)."""
+  from wavenets_amd import _lib
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=11, bias_range=0.3, **kw)
+  B, n = 5, 14
+  w = O.synthetic_waveform(B, model.receptive_field, seed=12).to(dev())
+  naive = model.generate(n, sample=w, use_queues=False, deterministic=det)
+  L = _lib.lib()
+  for key, val in ((0, 0), (23, 1), (25, 1), (26, 1), (27, 1), (6, 3), (6, 2)):
+    try:
+      L.wn_debug_set(key, val)
+      queued = model.generate(n, sample=w, use_queues=True, deterministic=det)
+    finally:
+      L.wn_debug_set(key, 0)
+    assert torch.equal(naive, queued), (key, val, (naive - queued).abs().max())
+
+
 def test_queued_generation_ring_wraparound():
   """More steps than the deepest ring has slots (dilation 32 -> 33 slots): every ring wraps at least twice."""
   kw = dict(blocks=6, channels=32, skip_channels=64, dilation_bound=64, final_layers_channels=[32],
