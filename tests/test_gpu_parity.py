@@ -844,6 +844,29 @@ def test_queued_generation_skip_wave_counts(skip_channels):
   assert torch.equal(naive, queued)          # continuous (mixture) outputs: equality is bit for bit
 
 
+def test_categorical_loss_kernel_forms_agree_bitwise():
+  """The persistent, next-row-prefetching loss kernel for <= 256 classes and the one-row-per-wave kernel (knob 28) run the
+  same arithmetic per row: loss, every gradient and the in-kernel sample_waveform draw are bit-identical (ragged row
+  count: more rows than one pass of the persistent grid, not a multiple of 4)."""
+  from wavenets_amd import _lib
+  kw = dict(MODEL_CASES['cat_small_fused'])
+  ocfg, params, model = make_pair(seed=3, bias_range=0.3, **kw)
+  x = O.synthetic_waveform(3, 2731 + 1, seed=21).to(dev())          # 8193 rows
+  L = _lib.lib()
+  res = []
+  for knob in (0, 1):
+    try:
+      L.wn_debug_set(28, knob)
+      model._sample_calls = 7                          # the draw's Philox offset: the same for both forms
+      loss, samp, _ = model.loss_and_grads(x, want_sample=True)
+      res.append((loss.clone(), None if samp is None else samp.clone(), model.flat_grads.clone()))
+    finally:
+      L.wn_debug_set(28, 0)
+  assert torch.equal(res[0][0][:2], res[1][0][:2])
+  assert torch.equal(res[0][2], res[1][2])
+  assert res[0][1] is not None and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize('name,det', [('cat_r64', True), ('cat_r64', False), ('cat_small_fused', False), ('mol', False)])
 def test_queued_generation_launch_variants_agree(name, det):
   """The queued sampler's launch variants draw the same samples as the sliding window: the first chain kernel (knob 23),

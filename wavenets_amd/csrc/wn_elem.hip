@@ -176,6 +176,99 @@ int wn_launch_softmax(const float* logits, float* probs, int64_t rows, int C, hi
 // sample_out (C <= 256 only): also draw sample_waveform(softmax(logits)) of the row (src/model.py:338,407-411)
 // from the probabilities already in registers -- the values wn_softmax_kernel would write, the draw
 // wn_sample_rand_cat_kernel would make from them.
+// C <= 256, the shape of every BASELINE categorical head: persistent waves, one row at a time per wave with the NEXT row's
+// logits and target already requested (the one-row-per-wave launch below spends most of a row waiting for its loads:
+// 172 us for 268 MB).  Per row the arithmetic is exactly that of wn_cat_loss_kernel's C <= 256 branch -- the target's
+// probability comes from the lane that holds it instead of a second, dependent load of the same logit -- and the max-abs
+// of the gradients is published once per wave.
+__global__ __launch_bounds__(256) void wn_cat_loss256_kernel(const float* logits, const int32_t* target,
+                                                             int64_t rows, int C, float gscale,
+                                                             float* loss_rows, float* g_logits, float* absmax_out,
+                                                             float* sample_out, float inv_lv, uint64_t seed, uint64_t offset) {
+  __shared__ float qs[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + w;
+  float vn[4];
+  int tn = 0;
+  auto fetch = [&](int64_t r) {
+    const float* l = logits + r * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vn[k] = lane + 64 * k < C ? l[lane + 64 * k] : -INFINITY;
+    tn = target[r];
+  };
+  if (row < rows) fetch(row);
+  float gmax = 0.f;
+  for (; row < rows; row += stride) {
+    float v[4], e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = vn[k];
+    int tgt = tn;
+    if (row + stride < rows) fetch(row + stride);     // in flight while this row is worked on
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = fmaxf(m, v[k]);
+    m = wn_wave_max(m);
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k] = lane + 64 * k < C ? expf(v[k] - m) : 0.f;
+      if (lane + 64 * k < C) z += e[k];
+    }
+    z = wn_wave_sum(z);
+    const float inv = 1.0f / z;
+    if (sample_out) {
+      float* qw = qs[w];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (lane + 64 * k < C) qw[lane + 64 * k] = e[k] * inv;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int drawn = wn_draw_cat_row((const float*)qw, C, lane, row, seed, offset);
+      if (lane == 0) sample_out[row] = (float)drawn * inv_lv - 1.0f;
+      __builtin_amdgcn_wave_barrier();                // the next row rewrites qw
+    }
+    float S = 0.f, A = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < C) {
+        const float q = e[k] * inv;
+        S += fminf(fmaxf(q, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+        if (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) A += q;
+      }
+    S = wn_wave_sum(S);
+    A = wn_wave_sum(A);
+    tgt = tgt < 0 ? 0 : (tgt >= C ? C - 1 : tgt);
+    const int tk = tgt >> 6;                          // wave-uniform: the lane tgt & 63 holds e[tk] = exp(l[tgt] - m)
+    const float et = __shfl(tk == 0 ? e[0] : tk == 1 ? e[1] : tk == 2 ? e[2] : e[3], tgt & 63);
+    const float qt = et * inv;
+    const float pt = fminf(fmaxf(qt, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+    const float ct = (qt >= WN_KERAS_EPS && qt <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+    if (lane == 0) loss_rows[row] = -(logf(pt) - logf(S));
+    if (g_logits) {
+      const float invS = 1.0f / S;
+      const float dot = A * invS - ct * qt / pt;     // sum_j g_j q_j
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        if (j < C) {
+          const float q = e[k] * inv;
+          const float c = (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+          float g = c * invS;
+          if (j == tgt) g -= ct / pt;
+          const float gl = gscale * q * (g - dot);
+          g_logits[row * C + j] = gl;
+          gmax = fmaxf(gmax, fabsf(gl));
+        }
+      }
+    }
+  }
+  if (g_logits && absmax_out) {
+    gmax = wn_wave_max(gmax);
+    if (lane == 0) wn_absmax_publish(absmax_out, gmax);
+  }
+}
+
 __global__ __launch_bounds__(256) void wn_cat_loss_kernel(const float* logits, const int32_t* target,
                                                           int64_t rows, int C, float gscale,
                                                           float* loss_rows, float* g_logits, float* absmax_out,
@@ -301,9 +394,15 @@ int wn_launch_cat_loss(const float* logits, const int32_t* target, int64_t rows,
                        float* sample_out, int bits, uint64_t seed, uint64_t offset) {
   if (rows <= 0) return WN_OK;
   if (sample_out && C > 256) { wn_set_error("cat_loss: the in-kernel sample draw needs <= 256 classes"); return WN_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(wn_cat_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
-                     target, rows, C, gscale, loss_rows, g_logits, absmax_out, sample_out,
-                     sample_out ? 1.0f / (float)(1 << (bits - 1)) : 0.f, seed, offset);
+  const float inv_lv = sample_out ? 1.0f / (float)(1 << (bits - 1)) : 0.f;
+  if (C <= 256 && wn_debug_get(28) != 1) {            // knob 28 = 1: one row per wave and launch slot
+    const int64_t wgs = std::min<int64_t>((rows + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(wn_cat_loss256_kernel, dim3((unsigned)wgs), dim3(256), 0, s, logits, target, rows, C, gscale,
+                       loss_rows, g_logits, absmax_out, sample_out, inv_lv, seed, offset);
+  } else {
+    hipLaunchKernelGGL(wn_cat_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
+                       target, rows, C, gscale, loss_rows, g_logits, absmax_out, sample_out, inv_lv, seed, offset);
+  }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
