@@ -223,6 +223,10 @@ int wn_loss_fn(int32_t head, const void* target, const float* pred, int64_t rows
  * probability tensor.  sample_out = NULL disarms.  WN_E_UNSUPPORTED (nothing armed): categorical head with a
  * deterministic draw or more than 1024 classes; use pred_out + wn_sample_waveform there. */
 int wn_plan_arm_step_sample(wn_plan* plan, float* sample_out, int32_t deterministic, uint64_t seed, uint64_t offset);
+/* wn_train_fwd_bwd in two calls: phases = 1 runs forward + loss (+ the armed step sample) and returns, phases = 2 runs the
+ * backward pass and the weight gradients of THAT forward pass (same arguments, same workspace), 3 = both (default).  A
+ * host driver uses the gap to queue its read-back of loss / metrics 4 ms before the step ends. */
+int wn_plan_set_train_phases(wn_plan* plan, int32_t phases);
 /* WaveNet.sample_waveform(pred, deterministic), src/model.py:393-503: (rows,C) -> (rows) */
 int wn_sample_waveform(int32_t head, const float* pred, int64_t rows, int32_t C,
                        int32_t num_mixtures, int32_t bits, int32_t deterministic, uint64_t seed,

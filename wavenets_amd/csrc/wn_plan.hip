@@ -110,6 +110,7 @@ struct wn_plan {
   int head_first = 0, cov_head_first = 0;   // job / coverage tables: the head's entries come last
   WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
   WnGenBlock gen_blk0[3]{};
+  int train_phases = 3;   // wn_plan_set_train_phases: bit 0 forward + loss (+ step sample), bit 1 backward + weight gradients
   int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
@@ -1730,6 +1731,12 @@ extern "C" int wn_eval_loss(wn_plan* p, const float* params, const float* x_full
   return WN_OK;
 }
 
+extern "C" int wn_plan_set_train_phases(wn_plan* p, int32_t phases) {
+  if (!p || phases < 1 || phases > 3) { wn_set_error("set_train_phases: 1 (forward + loss), 2 (backward), 3 (both)"); return WN_E_INVALID; }
+  p->train_phases = phases;
+  return WN_OK;
+}
+
 extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_full, const float* cond,
                                 int32_t B, int32_t T, int32_t global_batch, int32_t n_replicas, float* grads,
                                 float* loss_out, float* pred_out, float* workspace, int64_t ws_floats,
@@ -1743,13 +1750,20 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   float* ws = workspace;
   const int64_t rows = (int64_t)B * T;
   float* inputs = ws + L.probs;
+  // A caller may run the step as two calls (wn_plan_set_train_phases 1, then 2) and queue work of its own in between --
+  // the Python mirror reads the loss and the metrics back from there, 4 ms before the step ends.  Everything the second
+  // half needs lives in the workspace.
+  const int phases = p->train_phases;
+  int rc = WN_OK;
+  if (phases & 1) {
   hipLaunchKernelGGL(wn_shift_split_kernel, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 4096)), dim3(256), 0, s,
                      x_full, B, T, inputs, ws + L.yt);
   WN_HIP_CHECK(hipGetLastError());
   if (p->phase_on) (void)hipEventRecord(p->phase_ev[0], s);
-  int rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
+  rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
   if (rc) return rc;
   if (p->phase_on) (void)hipEventRecord(p->phase_ev[1], s);
+  }
   // running max-abs scalars of the gradient tensors (operand scaling of the split-precision GEMMs)
   float* am = ws + L.absmax;
   const int nf = (int)p->finals.size();
@@ -1757,6 +1771,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   float* am_gskip = am + nf;
   auto am_GU = [&](int b) { return am + nf + 1 + b; };
   auto am_GH = [&](int b) { return am + nf + 1 + p->N + b; };
+  if (phases & 1) {
   WN_HIP_CHECK(hipMemsetAsync(am, 0, L.n_absmax * sizeof(float), s));
   rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s);
   if (rc) return rc;
@@ -1783,7 +1798,23 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     }
     if (rc) return rc;
   }
+  // the step's other two scalars are complete here too: the L2 regulariser's loss term (src/model.py:331-334) and the
+  // range flag of the forward pass
+  if (p->c.l2_reg_factor > 0.f) {
+    float* norms = ws + L.loss_rows;   // free by now
+    rc = wn_launch_sumsq(params, p->d_kdesc, (int)p->kdesc.size(), norms, s);
+    if (rc) return rc;
+    rc = wn_launch_sum(norms, (int64_t)p->kdesc.size(), p->c.l2_reg_factor / (float)n_replicas, loss_out + 1, ws + L.sum_scratch, s);
+    if (rc) return rc;
+  } else {
+    rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
+    if (rc) return rc;
+  }
+  rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT, wn_debug_get(1) != 1, loss_out + 2, s);
+  if (rc) return rc;
   if (p->phase_on) (void)hipEventRecord(p->phase_ev[2], s);
+  }
+  if (!(phases & 2)) return WN_OK;
   const float* fragbase = ws + L.frag;
   float* slab = ws + L.slab;
 
@@ -2135,22 +2166,11 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       }
     }
   }
-  // ---- L2 regulariser, src/model.py:331-334 ----
+  // ---- L2 regulariser, src/model.py:331-334: its gradient (the loss term is formed with the loss, above) ----
   if (p->c.l2_reg_factor > 0.f) {
-    const float l2 = p->c.l2_reg_factor;
-    float* norms = ws + L.loss_rows;   // free by now
-    rc = wn_launch_sumsq(params, p->d_kdesc, (int)p->kdesc.size(), norms, s);
-    if (rc) return rc;
-    rc = wn_launch_sum(norms, (int64_t)p->kdesc.size(), l2 / (float)n_replicas, loss_out + 1, ws + L.sum_scratch, s);
-    if (rc) return rc;
-    rc = wn_launch_axpy_table(grads, params, p->d_kdesc, (int)p->kdesc.size(), 2.0f * l2 / (float)n_replicas, s);
-    if (rc) return rc;
-  } else {
-    rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
+    rc = wn_launch_axpy_table(grads, params, p->d_kdesc, (int)p->kdesc.size(), 2.0f * p->c.l2_reg_factor / (float)n_replicas, s);
     if (rc) return rc;
   }
-  rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT, wn_debug_get(1) != 1, loss_out + 2, s);
-  if (rc) return rc;
   if (p->phase_on) {
     if (!defer) (void)hipEventRecord(p->phase_ev[3], s);             // per-call weight gradients: no separate phase
     (void)hipEventRecord(p->phase_ev[4], s);

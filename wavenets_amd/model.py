@@ -133,6 +133,8 @@ class WaveNet(torch.nn.Module):
     self.loss_tracker = _Mean('loss')
     self.reg_loss = _Mean('reg_loss') if self.regularization else None
     self._sample_calls = 0
+    self.early_logs = True                # one replica: train_step reads its scalars back between forward and backward
+    self._log_mirror, self._log_event = None, None
     self._drop_step = 0                   # training calls made so far (dropout mask counter; saved by io.save_weights)
     self._fused_step_sample = True        # train_step draws its metric sample inside the library
     # structure handles (attribute names of the reference)
@@ -416,7 +418,7 @@ class WaveNet(torch.nn.Module):
       self._drop_step += 1
 
   def loss_and_grads(self, data, global_batch=None, n_replicas=None, want_pred=False, want_sample=False,
-                     _loss_in_bucket=False):
+                     _loss_in_bucket=False, _between=None):
     """Forward + loss + backward of this replica's rows (src/model.py:319-335).
 
     Fills ``self.flat_grads`` with d(sum_local l / B_global)/d(theta); returns
@@ -450,16 +452,30 @@ class WaveNet(torch.nn.Module):
     want_pred = want_pred or (want_sample and sample is None)
     pred = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device) if want_pred else None
     self._arm_dropout()
-    try:
+
+    def run():
       _lib.check(L.wn_train_fwd_bwd(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
                                     int(global_batch), int(n_replicas), _lib.ptr(self.flat_grads),
                                     _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    try:
+      if _between is None:
+        run()
+        out = (sample if sample is not None else self.sample_waveform(pred)) if want_sample else pred
+      else:
+        # the step as two calls: forward + loss, the caller's own work (its read-back of loss / metrics), backward
+        try:
+          L.wn_plan_set_train_phases(self._plan, 1)
+          run()
+          out = (sample if sample is not None else self.sample_waveform(pred)) if want_sample else pred
+          _between(loss, out, x[:, 1:, :])
+          L.wn_plan_set_train_phases(self._plan, 2)
+          run()
+        finally:
+          L.wn_plan_set_train_phases(self._plan, 3)
     finally:
       if sample is not None:
         L.wn_plan_arm_step_sample(self._plan, None, 0, 0, 0)      # never leave a stale pointer armed
-    if want_sample:
-      return loss, (sample if sample is not None else self.sample_waveform(pred)), x[:, 1:, :]
-    return loss, pred, x[:, 1:, :]
+    return loss, out, x[:, 1:, :]
 
   def train_step(self, data):
     """src/model.py:309-348.  Data-parallel: the flat gradient (and the loss scalars) are
@@ -489,8 +505,36 @@ class WaveNet(torch.nn.Module):
 
   def _train_step_once(self, data):
     want_metric = len(self._metrics_from_compilation) > 0
-    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True)
     from . import dp
+    if self.early_logs:
+      # loss, reg_loss, the range flag and the sample metrics are final right after the loss kernels.  Their device-to-host
+      # copy is queued THERE, between the forward and the backward half of the step, and the host waits for that copy
+      # only -- it returns with 4 ms of the step still queued and has the next step's launches out before the GPU runs
+      # dry (reading the scalars at the end of the step costs a bubble of ~80 us per step).  Data-parallel: a copy of the
+      # scalars is SUM-all-reduced there (a few floats); the gradient bucket still carries its own {loss, reg_loss, flag}
+      # tail for the device-side skip of the optimizer.
+      st = {}
+      world = self._world()
+
+      def between(loss, sample, y_true):
+        st['pending'] = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
+                         if hasattr(m, 'update_state_device')]
+        vec = torch.cat([loss] + [v for _, v in st['pending']])
+        if world > 1:
+          import torch.distributed as dist
+          dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+          vec[3:] /= world                             # metric values are means over a replica's rows (equal shares)
+        if self._log_mirror is None or self._log_mirror.numel() != vec.numel():
+          self._log_mirror = torch.empty(vec.numel(), dtype=torch.float32, pin_memory=True)
+          self._log_event = torch.cuda.Event()
+        self._log_mirror.copy_(vec, non_blocking=True)
+        self._log_event.record()
+      loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True, _between=between)
+      dp.allreduce_bucket(self._grad_bucket)            # gradients + {loss, reg_loss, range_flag}; no-op for a single replica
+      self.optimizer.apply_gradients(self, skip_flag=loss[2:3])
+      self._log_event.synchronize()
+      return self._log_mirror.tolist(), st['pending'], y_true, sample
+    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True)
     dp.allreduce_bucket(self._grad_bucket)              # gradients + {loss, reg_loss, range_flag}; no-op for a single replica
     self.optimizer.apply_gradients(self, skip_flag=loss[2:3])
     # metrics that can reduce on the device do so behind the optimizer; ONE read brings back loss, reg_loss, flag and them
