@@ -98,14 +98,18 @@ def generation_leg(dev, B: int = 8, n: int = 1000):
   res = {'workload': f'configs[1] weights, batch {B}, {n} samples per utterance after a {m.receptive_field}-sample window'}
   for name, queued, det, steps in (('queued_stochastic', True, False, n), ('queued_deterministic', True, True, n),
                                    ('sliding_window', False, True, 20)):
-    m.generate(3, sample=w, use_queues=queued, deterministic=det)
     ts = []
     for k in (steps // 4, steps):                      # two lengths: the difference leaves the priming pass out
-      torch.cuda.synchronize()
-      t0 = time.perf_counter()
-      m.generate(k, sample=w, use_queues=queued, deterministic=det)
-      torch.cuda.synchronize()
-      ts.append(time.perf_counter() - t0)
+      m.generate(k, sample=w, use_queues=queued, deterministic=det)     # (workspace of this length allocated)
+      best = None
+      for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.generate(k, sample=w, use_queues=queued, deterministic=det)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+      ts.append(best)
     per = (ts[1] - ts[0]) / (steps - steps // 4)
     res[name] = {'ms_per_sample_step': per * 1e3, 'samples_per_s_per_utterance': 1.0 / per, 'samples_per_s_aggregate': B / per}
   return res
