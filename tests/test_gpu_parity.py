@@ -844,6 +844,44 @@ def test_queued_generation_skip_wave_counts(skip_channels):
   assert torch.equal(naive, queued)          # continuous (mixture) outputs: equality is bit for bit
 
 
+@pytest.mark.parametrize('name', ['cat_small_fused', 'cond', 'mol'])
+def test_train_step_in_two_calls_equals_one_call(name):
+  """wn_plan_set_train_phases: forward + loss (+ step sample, L2 loss term, range flag) as one call and the backward half as
+  a second call -- with foreign work queued in between -- give the loss, the sample and every gradient of the single call
+  bit for bit; and train_step, which reads its scalars back in that gap, leaves the same parameters as the late read-back."""
+  from wavenets_amd import Adam, MeanSquaredError
+  kw = dict(MODEL_CASES[name])
+  kw['l2_reg_factor'] = 1e-3
+  B, T = 3, 401
+  res = []
+  for early in (False, True):
+    ocfg, params, model = make_pair(seed=5, bias_range=0.3, **kw)
+    x = O.synthetic_waveform(B, T + 1, seed=31).to(dev())
+    data = x
+    if kw.get('conditioning') is not None:
+      data = (x, torch.rand(B, kw['cond_inputs'], generator=torch.Generator().manual_seed(2)).to(dev()))
+    seen = {}
+
+    def between(loss, sample, y_true):
+      seen['loss'] = loss.clone()                       # complete here: loss, reg_loss, range flag
+      torch.zeros(1 << 20, device=dev()).add_(1.0)      # somebody else's kernels in the gap
+    model._sample_calls = 3
+    loss, samp, _ = model.loss_and_grads(data, want_sample=True, _between=between if early else None)
+    if early:
+      assert torch.equal(seen['loss'], loss)
+    grads = model.flat_grads.clone()
+    model.compile(optimizer=Adam(learning_rate=1e-3, clipnorm=1.0), metrics=[MeanSquaredError()])
+    model.early_logs = early
+    logs = [model.train_step(data) for _ in range(3)]
+    res.append((loss.clone(), samp.clone(), grads, model.flat_params.clone(), logs))
+  for a_, b_ in zip(res[0][:4], res[1][:4]):
+    assert torch.equal(a_, b_)
+  for la, lb in zip(res[0][4], res[1][4]):
+    assert la.keys() == lb.keys()
+    for k_ in la:
+      assert abs(la[k_] - lb[k_]) <= 1e-6 * max(1.0, abs(la[k_])), (k_, la[k_], lb[k_])
+
+
 def test_categorical_loss_kernel_forms_agree_bitwise():
   """The persistent, next-row-prefetching loss kernel for <= 256 classes and the one-row-per-wave kernel (knob 28) run the
   same arithmetic per row: loss, every gradient and the in-kernel sample_waveform draw are bit-identical (ragged row
