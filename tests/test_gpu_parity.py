@@ -917,7 +917,7 @@ def test_queued_generation_launch_variants_agree(name, det):
   w = O.synthetic_waveform(B, model.receptive_field, seed=12).to(dev())
   naive = model.generate(n, sample=w, use_queues=False, deterministic=det)
   L = _lib.lib()
-  for key, val in ((0, 0), (23, 1), (25, 1), (26, 1), (27, 1), (6, 3), (6, 2)):
+  for key, val in ((0, 0), (23, 1), (25, 1), (26, 1), (27, 1), (27, 2), (6, 3), (6, 2)):
     try:
       L.wn_debug_set(key, val)
       queued = model.generate(n, sample=w, use_queues=True, deterministic=det)

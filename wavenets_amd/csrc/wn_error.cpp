@@ -38,7 +38,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   25  = 1: generation chain kernel without its L2 helper workgroups
 //   26  = 1: the generation pre kernel as its own launch (not inside the previous step's head launch)
 //   28  = 1: categorical loss on the one-row-per-wave kernel (no persistent waves with the next row prefetched)
-//   27  = 1: the categorical sampling tail of a generation step as its own launch (not inside the head launch)
+//   27  = 1: the categorical sampling tail of a generation step as its own launch (not inside the head launch);
+//       = 2: inside the head launch also for more than 8 utterances
 //   24  = 1: the generation chain kernel stamps its phases with s_memtime for blocks 8..11 (wn_debug_gen_ts reads them)
 // thread-local: a caller that switches kernel variants (the range guard's exact-fp32 retry, tools/ A/B runs, tests)
 // affects the launches of its own thread only

@@ -415,20 +415,23 @@ __global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenS
 // Chain kernel, second form: weights travel in REGISTERS, several blocks ahead.
 // A kernel starts with a cold L2 (the per-XCD L2s are invalidated at kernel boundaries), so every weight line of a
 // generation step comes from the memory side, ~2 us away -- about two blocks' worth of arithmetic.  One workgroup per 32
-// utterances, 2 waves per SIMD (256 registers a lane), three exclusive roles, each with its own copy of the block loop
-// (same barrier count) so that its registers are allocated apart from the others':
-//   chain wave w < JU      phase A: u tile w = u0 + W_{k-1}^T x; phase B: gated activation of z k-step w.  Holds the
-//                          newest-tap fragments and the u0 image of ITS tile for blocks b .. b+2.
+// utterances, at most 10 waves (168 registers a lane), three exclusive roles, each with its own copy of the block loop
+// (same barrier count: two a block, (2) z operands visible, (3) x operands visible) so that its registers are allocated
+// apart from the others':
+//   chain wave w < JU      phase A: a MIXED u tile (16 filter channels and their 16 gate channels) = u0 + W_{k-1}^T x, then
+//                          the gate in registers: z k-step w.  Holds the newest-tap fragments and the u0 image of ITS
+//                          tile for blocks b, b + 1.  (Plain tiles would need the u tiles exchanged through LDS and a
+//                          barrier between phase A and the gate: 0.069 -> 0.061 ms per step without.)
 //   conv1 wave j < R / 32  carries the block input x; phase C: o tile j = b_r + W_r^T z, x_next = o (+ x).  Holds the
-//                          conv1 fragments and bias of its tile for blocks b .. b+2.
+//                          conv1 fragments and bias of its tile for blocks b, b + 1.
 //   skip wave s            two column tiles of the folded skip contraction, acc += W_{s,b}^T z (k order = block order):
 //                          tile 2s right after z_b is visible, tile 2s+1 one phase later (z operands are double-buffered)
 //                          while the chain waves are in their transcendental phase and the MFMA pipe is idle.
 // A workgroup's vector memory operations go through one 64 B / clock address pipe -- 128 KB of weights a block is ~2000
 // clocks of it, against ~2600 of arithmetic -- and a wave that issues into a full pipe stalls.  So no wave issues its
 // refill between its arithmetic and the barrier that ends its phase: the chain waves issue theirs in phase C (when they
-// idle), the conv1 waves in phase A, the skip waves in phases A and B.  LDS only holds the exchange
-// buffers (u tiles, x operands, 2 x z operands) and a copy of the block table.
+// idle), the conv1 waves in phase A, the skip waves in phases A and B.  LDS only holds the exchange buffers (x operands,
+// 2 x z operands) and a copy of the block table.
 #define WN_GEN_CHAIN_MAX_BLOCKS 128
 // acc += W^T b over NK k-steps (hi|lo B operands in LDS, 2 KB a k-step), the three products of a k-step in the order of
 // the training kernels.  The operands of k-step k + 1 are requested BEFORE the products of k-step k are issued: written
@@ -552,26 +555,36 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
   };
 
   if (is_chain) {
-    // ================= chain waves: phase A (u tile `wave`) and phase B (z k-step `wave`) =================
+    // ================= chain waves: phase A and the gate, z k-step `wave` =================
+    // Wave w owns a MIXED row tile of the gated conv: rows 0..15 = filter channels 16 w .. 16 w + 15, rows 16..31 = the
+    // gate channels of the same 16 -- the two 16-row halves of image tiles w / 2 and D32 + w / 2.  A lane's 16 accumulators
+    // are then 8 filter values and THEIR 8 gate values, the gate runs in registers, and the u tiles never go through LDS
+    // (no barrier between phase A and the gate).  Only the lanes' fetch addresses differ from a plain tile: every output
+    // element is the same dot product over the same operands in the same order.
     // per iteration: 2 KSR + 4 loads (fetch), then 2 stores (z row) -- see the wait in phase A
     gn_h8 wa[NS][KSR][2];
     f32x4 u0q[NS][4];                                 // the u0 images of the tile (dead columns read column 0's lines)
     const int ulane = live ? lane : h * 32;
+    const int half16 = 16 * (wave & 1);               // which 16 rows of the image tiles
+    const int wlane = (tl < 16 ? (wave >> 1) : D32 + (wave >> 1)) * 128 + half16 + (tl & 15) + 32 * h;   // tile * 128 + lane inside it
     auto fetch_a = [&](auto sc, int b, int64_t w16d_off) {
       constexpr int s = decltype(sc)::value;
       const bool real = b < nblocks;                  // past the end: every lane on one line of the parameters
-      const gn_h8* wd = real ? reinterpret_cast<const gn_h8*>(a.ws + w16d_off) + (int64_t)KS0 * JU * 128 + lane
+      const gn_h8* wd = real ? reinterpret_cast<const gn_h8*>(a.ws + w16d_off) + (int64_t)KS0 * JU * 128 + wlane
                              : reinterpret_cast<const gn_h8*>(a.params);
       const int m = real ? 64 : 0;
 #pragma unroll
       for (int kk = 0; kk < KSR; ++kk) {
-        gn_ld16(wa[s][kk][0], wd + ((kk * JU + wave) * 2 + 0) * m);
-        gn_ld16(wa[s][kk][1], wd + ((kk * JU + wave) * 2 + 1) * m);
+        gn_ld16(wa[s][kk][0], wd + (kk * JU * 2 + 0) * m);
+        gn_ld16(wa[s][kk][1], wd + (kk * JU * 2 + 1) * m);
       }
-      const f32x4* u0 = real ? reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * a.ntiles + tile) * (JU * 4) + wave * 4) * 64 + ulane
+      // accumulator quads 0, 1 = quads 2 (w & 1), 2 (w & 1) + 1 of u0 tile w / 2; quads 2, 3 = the same of tile D32 + w / 2
+      const f32x4* u0 = real ? reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * a.ntiles + tile) * (JU * 4) + (wave >> 1) * 4 + 2 * (wave & 1)) * 64 + ulane
                              : reinterpret_cast<const f32x4*>(a.params);
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) gn_ld16(u0q[s][rq], u0 + rq * m);
+      gn_ld16(u0q[s][0], u0);
+      gn_ld16(u0q[s][1], u0 + m);
+      gn_ld16(u0q[s][2], u0 + D32 * 4 * m);
+      gn_ld16(u0q[s][3], u0 + (D32 * 4 + 1) * m);
     };
     wn_static_for<NS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
@@ -589,7 +602,6 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
     });
     copy_table();
     GN_BARRIER();
-    const int jz = wave >> 1, rq0 = 2 * (wave & 1);
     for (int b0 = 0; b0 < nblocks; b0 += NS)
       wn_static_for<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -608,15 +620,10 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
             u[4 * rq + 0] = u0q[s][rq].x; u[4 * rq + 1] = u0q[s][rq].y; u[4 * rq + 2] = u0q[s][rq].z; u[4 * rq + 3] = u0q[s][rq].w;
           }
           gn_mac<KSR>(u, wa[s], reinterpret_cast<const gn_h8*>(xop) + lane);
-          f32x4* ub = reinterpret_cast<f32x4*>(ubuf) + (wave * 4) * 64 + lane;
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
           if (wave == 0) GN_TS(0, b, 2);
-          GN_BARRIER();                               // (1) u tiles visible
-          if (wave == 0) GN_TS(0, b, 3);
-          const f32x4* uf = reinterpret_cast<const f32x4*>(ubuf) + (jz * 4 + rq0) * 64 + lane;
-          const f32x4* ug = reinterpret_cast<const f32x4*>(ubuf) + ((jz + D32) * 4 + rq0) * 64 + lane;
-          const f32x4 f0 = uf[0], f1 = uf[64], g0 = ug[0], g1 = ug[64];
+          // the gate: accumulators 0..7 are filter channels 16 w + {4h.., 8 + 4h..}, 8..15 their gate channels
+          const f32x4 f0 = {u[0], u[1], u[2], u[3]}, f1 = {u[4], u[5], u[6], u[7]};
+          const f32x4 g0 = {u[8], u[9], u[10], u[11]}, g1 = {u[12], u[13], u[14], u[15]};
           f32x4 z0, z1;
           z0.x = wn_tanh_fast(f0.x) * wn_sigmoid_fast(g0.x); z0.y = wn_tanh_fast(f0.y) * wn_sigmoid_fast(g0.y);
           z0.z = wn_tanh_fast(f0.z) * wn_sigmoid_fast(g0.z); z0.w = wn_tanh_fast(f0.w) * wn_sigmoid_fast(g0.w);
@@ -706,8 +713,6 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
               *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
           }
           if (cw == 0) GN_TS(1, b, 0);
-          GN_BARRIER();                               // (1)
-          if (cw == 0) GN_TS(1, b, 1);
           GN_BARRIER();                               // (2) z operands visible
           if (cw == 0) GN_TS(1, b, 2);
           gn_vmwait<(NS - 1) * (2 * KS2 + 4)>();   // only LOADS count as younger: stores retire out of order with them
@@ -788,17 +793,14 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       settle(w1);
       copy_table();
       GN_BARRIER();
-      GN_BARRIER();                                   // (1) of block 0
-      GN_BARRIER();                                   // (2)
+      GN_BARRIER();                                   // (2) of block 0
       landed(w0);
       mac(acc0, w0, 0);
       GN_BARRIER();                                   // (3)
       pre_skip(w0, 1, t0);
       for (int b = 1; b < nblocks; ++b) {
-        if (sw == 0) GN_TS(2, b, 0);
-        GN_BARRIER();                                 // (1)
         if (sw == 0) GN_TS(2, b, 1);
-        landed(w1);                                   // tile t1 of block b - 1, then its refill (phase B: the address pipe is idle)
+        landed(w1);                                   // tile t1 of block b - 1, then its refill (under the chain waves' phase A and gate)
         if (sw == 0) GN_TS(2, b, 2);
         mac(acc1, w1, (b - 1) & 1);
         pre_skip(w1, b, t1);
@@ -821,7 +823,6 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       copy_table();
       GN_BARRIER();
       for (int b = 0; b < nblocks; ++b) {
-        GN_BARRIER();                                 // (1)
         GN_BARRIER();                                 // (2) z operands of block b visible
         landed(w0);
         mac(acc0, w0, b & 1);
