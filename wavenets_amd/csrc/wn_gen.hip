@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
   using S = GnShape<R32, D32, KS>;
   constexpr int R = S::R, D = S::D, JU = S::JU, KSR = S::KSR, KS0 = S::KS0, KS2 = S::KS2;
   constexpr int NS = 2;                               // register sets of the chain / conv1 waves (blocks in flight)
-  constexpr int UB_BYTES = S::U0_BYTES;
+  constexpr int UB_BYTES = WN_GEN_CHAIN_MAX_BLOCKS * R * 4;   // conv1 biases of every block (filled once by the conv1 waves)
   constexpr int XOP_BYTES = KSR * 2048, ZOP_BYTES = KS2 * 2048;
   constexpr int TBL_BYTES = WN_GEN_CHAIN_MAX_BLOCKS * (int)sizeof(WnGenBlock);
   __shared__ __attribute__((aligned(16))) unsigned char smem[UB_BYTES + XOP_BYTES + 2 * ZOP_BYTES + TBL_BYTES];
@@ -653,10 +653,10 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
     gn_vmwait<0>();                                   // the fetches past the last block: nothing may still be in flight
   } else if (is_conv1) {                              // when their registers are reused
     // ================= conv1 waves: carry the block input x; phase C (o tile `cw`) =================
-    // per iteration: 4 stores (ring) at the top, 2 KS2 + 4 loads (fetch) at the bottom -- see the wait in phase C
+    // per iteration: 4 stores (ring) at the top, 2 KS2 loads (fetch) at the bottom -- see the wait in phase C
     gn_h8 wc[NS][KS2][2];
-    f32x4 bq[NS][4];                                  // the bias of the tile as an accumulator image
-    auto fetch_c = [&](auto sc, bool real, int64_t w16r_off, int64_t bias_r_off) {
+    float* const bias_l = reinterpret_cast<float*>(ubuf);   // [block][R]; wave cw fills and reads columns 32 cw .. 32 cw + 31
+    auto fetch_c = [&](auto sc, bool real, int64_t w16r_off) {
       constexpr int s = decltype(sc)::value;
       const gn_h8* wr = real ? reinterpret_cast<const gn_h8*>(a.ws + w16r_off) + lane : reinterpret_cast<const gn_h8*>(a.params);
       const int m = real ? 64 : 0;
@@ -665,24 +665,42 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
         gn_ld16(wc[s][ks][0], wr + ((ks * R32 + cw) * 2 + 0) * m);
         gn_ld16(wc[s][ks][1], wr + ((ks * R32 + cw) * 2 + 1) * m);
       }
-      const float* br = real ? a.params + bias_r_off + 32 * cw + 4 * h : a.params;
-      const int mb = real ? 8 : 0;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) gn_ld16(bq[s][rq], br + mb * rq);
     };
     wn_static_for<NS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      fetch_c(sc, s < nblocks, a.blk0[s].w16r_off, a.blk0[s].bias_r_off);
+      fetch_c(sc, s < nblocks, a.blk0[s].w16r_off);
     });
+    // the conv1 biases of ALL blocks, once: 4 vector-memory operations a block and wave less than fetching them with the
+    // fragments.  Wave cw keeps its own 32 columns (written and read by the same wave: LDS operations of a wave are ordered).
+    // Requested here, with the first fragments, so that the kernel's start pays one cold round trip for both.
+    constexpr int NBL = WN_GEN_CHAIN_MAX_BLOCKS * 32 / 64;
+    float bl_[NBL];
+    if (a.bias_r_stride != 0) {
+#pragma unroll
+      for (int q = 0; q < NBL; ++q) {
+        const int i = lane + 64 * q, bb = min(i >> 5, nblocks - 1), c = 32 * cw + (i & 31);   // (odd block counts: clamped)
+        if (64 * q < nblocks * 32) bl_[q] = a.params[a.bias_r_off0 + (int64_t)bb * a.bias_r_stride + c];   // wave-uniform
+      }
+    }
     gn_vmwait<0>();                                   // as in the chain role
     wn_static_for<NS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) { gn_landed(wc[s][ks][0]); gn_landed(wc[s][ks][1]); }
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) gn_landed(bq[s][rq]);
     });
     copy_table();
+    if (a.bias_r_stride != 0) {
+#pragma unroll
+      for (int q = 0; q < NBL; ++q) {
+        const int i = lane + 64 * q;
+        if (i < nblocks * 32) bias_l[(i >> 5) * R + 32 * cw + (i & 31)] = bl_[q];
+      }
+    } else {
+      for (int i = lane; i < nblocks * 32; i += 64) {
+        const int bb = i >> 5, c = 32 * cw + (i & 31);
+        bias_l[bb * R + c] = a.params[a.blocks[bb].bias_r_off + c];
+      }
+    }
     // ---- input causal conv (C_in = 1): the k-ordered fma chain of the fp32 MFMA path, then + bias ----
     f32x16 x;
     {
@@ -715,16 +733,15 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
           if (cw == 0) GN_TS(1, b, 0);
           GN_BARRIER();                               // (2) z operands visible
           if (cw == 0) GN_TS(1, b, 2);
-          gn_vmwait<(NS - 1) * (2 * KS2 + 4)>();   // only LOADS count as younger: stores retire out of order with them
+          gn_vmwait<(NS - 1) * 2 * KS2>();          // only LOADS count as younger: stores retire out of order with them
           if (cw == 0) GN_TS(1, b, 3);
 #pragma unroll
           for (int ks = 0; ks < KS2; ++ks) { gn_landed(wc[s][ks][0]); gn_landed(wc[s][ks][1]); }
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) gn_landed(bq[s][rq]);
           f32x16 o;
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
-            o[4 * rq + 0] = bq[s][rq].x; o[4 * rq + 1] = bq[s][rq].y; o[4 * rq + 2] = bq[s][rq].z; o[4 * rq + 3] = bq[s][rq].w;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + b * R + 32 * cw + 8 * rq + 4 * h);
+            o[4 * rq + 0] = bv.x; o[4 * rq + 1] = bv.y; o[4 * rq + 2] = bv.z; o[4 * rq + 3] = bv.w;
           }
           gn_mac<KS2>(o, wc[s], reinterpret_cast<const gn_h8*>(zop + (b & 1) * ZOP_BYTES) + lane);
 #pragma unroll
@@ -734,8 +751,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
           GN_BARRIER();                               // (3) x operands visible
           if (cw == 0) GN_TS(1, b, 5);
           {                                           // refill of set s, issued while the conv1 waves idle (phases A, B)
-            const WnGenBlock& nb = tbl[min(b + NS, nblocks - 1)];
-            fetch_c(sc, b + NS < nblocks, nb.w16r_off, nb.bias_r_off);
+            fetch_c(sc, b + NS < nblocks, tbl[min(b + NS, nblocks - 1)].w16r_off);
           }
           if (cw == 0) GN_TS(1, b, 6);
         }
@@ -781,13 +797,39 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     // The two loops below contain no conditional fetch: a fetch under a branch makes the fetched registers a phi of two
     // definitions, and the copies that resolve it would read registers whose load is still in flight.
-    pre_skip(w0, 0, t0);
     auto settle = [&](gn_h8 (&w)[KS2][2]) {          // as in the chain role
       gn_vmwait<0>();
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) { gn_landed(w[ks][0]); gn_landed(w[ks][1]); }
     };
-    if (has1) {
+    if (has1 && a.skip_tiles <= 4) {
+      // at most two skip waves: they sit on SIMDs 2 and 3, the conv1 waves on 0 and 1 -- both tiles run in phase C without
+      // touching the conv1 waves' MFMA pipe, and nothing of the skip role stands between the chain waves' gate and
+      // barrier (2).  Both refills in phase A.
+      pre_skip(w0, 0, t0);
+      pre_skip(w1, 0, t1);
+      settle(w0);
+      settle(w1);
+      copy_table();
+      GN_BARRIER();
+      for (int b = 0; b < nblocks; ++b) {
+        if (sw == 0) GN_TS(2, b, 3);
+        GN_BARRIER();                                 // (2) z operands of block b visible
+        if (sw == 0) GN_TS(2, b, 4);
+        landed(w0);                                   // (younger: w1's fetch)
+        mac(acc0, w0, b & 1);
+        settle(w1);
+        mac(acc1, w1, b & 1);
+        if (sw == 0) GN_TS(2, b, 5);
+        GN_BARRIER();                                 // (3)
+        if (sw == 0) GN_TS(2, b, 6);
+        pre_skip(w0, b + 1, t0);
+        pre_skip(w1, b + 1, t1);
+        if (sw == 0) GN_TS(2, b, 7);
+      }
+      gn_vmwait<0>();                                 // the fetches past the last block
+    } else if (has1) {
+      pre_skip(w0, 0, t0);
       pre_skip(w1, 0, t1);
       settle(w0);
       settle(w1);
@@ -819,6 +861,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       landed(w1);                                     // tile t1 of the last block (its z half is not rewritten)
       mac(acc1, w1, (nblocks - 1) & 1);
     } else {
+      pre_skip(w0, 0, t0);
       settle(w0);
       copy_table();
       GN_BARRIER();

@@ -197,6 +197,7 @@ struct WnGenStepArgs {
   int32_t B, nblocks, residual;
   int32_t ntiles;                  // utterance tiles = chain workgroups (the chain launch appends helper workgroups)
   unsigned long long* ts;          // phase stamps (debug switch 24) or null
+  int64_t bias_r_off0, bias_r_stride;   // conv1 bias of block b at params + off0 + b * stride (stride 0: not uniform, read the table)
   WnGenBlock blk0[3];              // blocks[0..2] by value (the first fetches do not wait for the table)
 };
 // queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)

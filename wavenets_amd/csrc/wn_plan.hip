@@ -110,6 +110,7 @@ struct wn_plan {
   int head_first = 0, cov_head_first = 0;   // job / coverage tables: the head's entries come last
   WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
   WnGenBlock gen_blk0[3]{};
+  int64_t gen_bias_stride = 0;
   int train_phases = 3;   // wn_plan_set_train_phases: bit 0 forward + loss (+ step sample), bit 1 backward + weight gradients
   int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
@@ -2408,6 +2409,10 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     WN_HIP_CHECK(hipMemcpy(p->d_gen, tab.data(), tab.size() * sizeof(WnGenBlock), hipMemcpyHostToDevice));
     p->gen_B = B;
     for (int b = 0; b < 3; ++b) p->gen_blk0[b] = tab[std::min(b, p->N - 1)];
+    // conv1 biases at a uniform stride (every block has the same tensors): the chain kernel fetches them without the table
+    p->gen_bias_stride = p->N > 1 ? tab[1].bias_r_off - tab[0].bias_r_off : 1;
+    for (int b = 1; b < p->N; ++b)
+      if (tab[b].bias_r_off != tab[0].bias_r_off + (int64_t)b * p->gen_bias_stride) p->gen_bias_stride = 0;
   }
   const int hc0 = (gfold && p->c.use_skip) ? skipw : p->Hin;
   // the whole head in one launch when every layer is one the split-precision rows GEMM would take
@@ -2430,6 +2435,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       ga.causal_b = params + p->tensors[p->causal.bias_t].off;
       ga.u0_off = G.u0;
       for (int b = 0; b < 3; ++b) ga.blk0[b] = p->gen_blk0[b];
+      ga.bias_r_off0 = p->gen_blk0[0].bias_r_off; ga.bias_r_stride = p->gen_bias_stride;
       if (skip_in_chain) {
         ga.skip_w16_off = G.prime + L.frag + skip_img;
         ga.skip_bias_off = G.prime + (gfold ? L.bfold : L.bias_sum);
