@@ -926,6 +926,29 @@ def test_queued_generation_launch_variants_agree(name, det):
     assert torch.equal(naive, queued), (key, val, (naive - queued).abs().max())
 
 
+@pytest.mark.parametrize('skip_channels,finals', [(160, [64]), (256, [128, 256]), (96, [32]), (192, [64, 64])])
+def test_queued_generation_unfolded_skip_contraction(skip_channels, finals):
+  """With the fold switched off (knob 21) the chain kernel carries the reference's full-width skip contraction: 3, 5, 6 and
+  8 column tiles, i.e. two to four skip waves of two tiles each on the two-phase schedule (the folded default needs at
+  most four tiles and runs both in phase C)."""
+  from wavenets_amd import _lib
+  kw = dict(blocks=5, channels=64 if skip_channels == 256 else 32, skip_channels=skip_channels, dilation_bound=8,
+            final_layers_channels=finals, activation='leaky_relu', bits=8)
+  ocfg, params, model = make_pair(seed=13, bias_range=0.3, **kw)
+  w = O.synthetic_waveform(5, model.receptive_field, seed=14).to(dev())
+  L = _lib.lib()
+  try:
+    L.wn_debug_set(21, 1)
+    naive = model.generate(12, sample=w, use_queues=False, deterministic=True)
+    queued = model.generate(12, sample=w, use_queues=True, deterministic=True)
+    queued_s = model.generate(12, sample=w, use_queues=True, deterministic=False)
+    naive_s = model.generate(12, sample=w, use_queues=False, deterministic=False)
+  finally:
+    L.wn_debug_set(21, 0)
+  assert torch.equal(naive, queued)
+  assert torch.equal(naive_s, queued_s)
+
+
 def test_queued_generation_ring_wraparound():
   """More steps than the deepest ring has slots (dilation 32 -> 33 slots): every ring wraps at least twice."""
   kw = dict(blocks=6, channels=32, skip_channels=64, dilation_bound=64, final_layers_channels=[32],
