@@ -42,5 +42,6 @@ if __name__ == '__main__':
   tree = io._tree_from_model(Model())
   tree['loss_tracker'] = {'vars': {'0': np.float32(1.5), '1': np.float32(2.0)}}     # a metric's state: ignored on import
   tree['prepare_target'] = {'vars': {}}                                            # a layer without variables
+  tree['mapping']['layers']['identity'] = {'vars': {}}                             # the Sequential's trailing Identity
   h5.write_h5(out, tree)
   print(out, os.path.getsize(out), 'bytes')

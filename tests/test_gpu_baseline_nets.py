@@ -133,6 +133,19 @@ def test_30_block_activations_loss_and_all_gradients(name, math_mode):
     branch.append(ha >= 0)                               # leaky_relu: the product's side of the kink
   # ---- loss, data gradients at the skip sum and at every block input, every parameter gradient ----
   loss_ref, grads_ref, g_skip_ref, g_h_ref, n_kink = _oracle_grads(name, branch)
+  # The oracle may take the product's side of a leaky_relu kink only where ITS OWN fp64 pre-activation lies within
+  # KINK_TOL (= the activation tolerance) of 0; that must stay a handful of elements (0-2 of 2.7 M in practice), or
+  # a sign bug near zero could hide behind it.  Re-derived here from the oracle's pre-activations, not trusted.
+  n_head = sum(a.numel() for a in inter['head_pre'])
+  n_over, worst_over = 0, 0.0
+  for a, br in zip(inter['head_pre'], branch):
+    over = (a >= 0) != br
+    n_over += int(over.sum())
+    if over.any():
+      worst_over = max(worst_over, a[over].abs().max().item())
+  assert n_over == n_kink, (n_over, n_kink)                 # every disagreement is one the oracle resolved as a kink ...
+  assert worst_over < O.KINK_TOL, worst_over                # ... i.e. none lies outside the undecided band
+  assert n_kink <= 8 and n_kink <= 1e-5 * n_head, (name, math_mode, n_kink, n_head)
   assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item())), (loss[0].item(), loss_ref.item())
   if folded:
     # d loss / d skip sum = (d loss / d a) W_f0^T, a = pre-activation of the first head conv (kept in the workspace)

@@ -53,7 +53,8 @@ def test_fixture_reads_back_and_maps_onto_the_model_variables():
   m = _load_fixture_module()
   tree = h5.read_h5(FIXTURE)
   assert set(tree['wavenet_blocks']) == {'wave_net_layer', 'wave_net_layer_1'}
-  assert set(tree['final']) == {'conv1d', 'conv1d_1'} and set(tree['mapping']) == {'dense'}
+  assert set(tree['final']) == {'conv1d', 'conv1d_1'}
+  assert set(tree['mapping']) == {'layers'} and set(tree['mapping']['layers']) == {'dense', 'identity'}
   k = tree['wavenet_blocks']['wave_net_layer_1']['dilated_stack']['conv1d']['vars']['0']
   assert k.dtype == np.float32 and k.shape == (2, 4, 8)
   assert tree['prepare_target']['vars'] == {}
@@ -65,6 +66,7 @@ def test_fixture_reads_back_and_maps_onto_the_model_variables():
   regenerated = io._tree_from_model(model)
   regenerated['loss_tracker'] = {'vars': {'0': np.float32(1.5), '1': np.float32(2.0)}}
   regenerated['prepare_target'] = {'vars': {}}
+  regenerated['mapping']['layers']['identity'] = {'vars': {}}
   assert h5._Writer().finish(regenerated) == open(FIXTURE, 'rb').read()
 
 
@@ -74,7 +76,23 @@ def test_keras_paths():
   assert io.keras_path('block12/dil2/bias') == 'wavenet_blocks/wave_net_layer_12/dilated_stack/conv1d_2/vars/1'
   assert io.keras_path('block3/conv_skip/kernel') == 'wavenet_blocks/wave_net_layer_3/conv_skip/vars/0'
   assert io.keras_path('final2/kernel') == 'final/conv1d_2/vars/0'
-  assert io.keras_path('mapping1/bias') == 'mapping/dense_1/vars/1'
+  assert io.keras_path('mapping1/bias') == 'mapping/layers/dense_1/vars/1'
+
+
+def test_mapping_network_loads_with_and_without_the_sequential_layers_level():
+  # keras.Sequential (src/model.py:142-148) saves its children under 'layers'; a flat 'mapping/dense' tree (what round 2
+  # of this build wrote) must still load, and variable-free children (Identity) must not shift the member index
+  m = _load_fixture_module()
+  model = m.Model()
+  tree = io._tree_from_model(model)
+  assert 'layers' in tree['mapping']
+  tree['mapping']['layers']['identity'] = {'vars': {}}
+  a = io._weights_from_tree(model, tree)
+  flat = dict(tree)
+  flat['mapping'] = {k: v for k, v in tree['mapping']['layers'].items()}
+  b = io._weights_from_tree(model, flat)
+  assert all(np.array_equal(x, y) for x, y in zip(a, b))
+  assert np.array_equal(a[-2], m.value(len(m.SHAPES) - 2, (5, 3)))
 
 
 def test_h5_round_trip_large_groups_dtypes_and_errors(tmp_path):

@@ -1,0 +1,148 @@
+// Skeleton probe for a streamed-weights fused block kernel (R = D = 128): what does one CU sustain when a workgroup
+// (a) streams a shared, L2-resident weight image through an LDS ring by LDS-DMA, (b) streams private activation rows
+// from HBM, (c) stores output tiles, (d) runs the products -- alone and together?
+//   hipcc --offload-arch=gfx950 -O3 tools/stream_probe.hip -o tools/stream_probe && tools/stream_probe
+// One workgroup of 8 waves per CU, one raw barrier per chunk (chunk = 16 KiB of weights = one k-step of 8 row tiles).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define DMA(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                                        (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+// WPC / XPC: 1 KiB DMA instructions per wave and chunk for weights / activations; SPT: 1 KiB store instructions per wave
+// and tile (a tile = NCH chunks); MF: MFMAs per wave and chunk; LR: 1 = read the weight fragments from LDS
+template <int WPC, int XPC, int SPT, int MF, int LR, int NCH>
+__global__ __launch_bounds__(512, 2) void probe(const f32x4* __restrict__ w, int wchunks, const f32x4* __restrict__ x,
+                                                size_t xmask, f32x4* __restrict__ y, size_t ymask, int ntiles, float* out,
+                                                unsigned long long* cyc) {
+  constexpr int WCH = (WPC > 0 ? WPC : 1) * 8 * 1024, XB = (XPC > 0 ? XPC : 1) * 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WCH + 8 * 4 * XB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* xbuf = smem + 4 * WCH + wave * 4 * XB;
+  f32x16 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  f32x4 sink = {0, 0, 0, 0};
+  const size_t wgbase = (size_t)blockIdx.x << 20;   // 16 MiB apart (in 16-byte pieces)
+  size_t xc = 0, yc = 0;
+  auto wdma = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < WPC; ++i) {
+      const f32x4* src = w + ((size_t)(c % wchunks) * WPC * 8 + i * 8 + wave) * 64 + lane;
+      DMA(src, smem + (c & 3) * WCH + (i * 8 + wave) * 1024);
+    }
+  };
+  auto xdma = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < XPC; ++i) {
+      const size_t o = (wgbase + ((xc++) * 8 + wave) * 64) & xmask;
+      DMA(x + o + lane, xbuf + (c & 3) * XB + i * 1024);
+    }
+  };
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  int c = 0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();
+    wdma(c); xdma(c); wdma(c + 1); xdma(c + 1); xdma(c + 2);
+    for (int k = 0; k < NCH; ++k, ++c) {
+      wdma(c + 2);
+      xdma(c + 3);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPC + 3 * XPC) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const h8* wl = reinterpret_cast<const h8*>(smem + (c & 3) * WCH) + lane;
+      h8 bh = {1, 1, 1, 1, 1, 1, 1, 1};
+      if (XPC > 0) {
+        const f32x4 xv = *(reinterpret_cast<const f32x4*>(xbuf + (c & 3) * XB) + lane);
+        bh[0] = (_Float16)xv.x; bh[1] = (_Float16)xv.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        h8 ah = bh, al = bh;
+        if (LR && WPC > 0) { ah = wl[((j % (WPC * 4)) * 2 + 0) * 64]; al = wl[((j % (WPC * 4)) * 2 + 1) * 64]; }
+        if (MF >= 8 * 1 && j < MF / 3 + (MF % 3 ? 1 : 0)) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, al, acc[j], 0, 0, 0);
+        } else if (LR) {
+          sink.x += (float)ah[0] + (float)al[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    c += 3;
+    // epilogue stores: SPT KiB per wave
+#pragma unroll 8
+    for (int i = 0; i < SPT; ++i) {
+      const size_t o = (wgbase + ((yc++) * 8 + wave) * 64) & ymask;
+      f32x4 v = {acc[i & 7][0], acc[i & 7][1], acc[i & 7][2], sink.x};
+      y[o + lane] = v;
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+  float s = sink.x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += acc[j][0];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <int WPC, int XPC, int SPT, int MF, int LR, int NCH>
+static void run(const char* name, const f32x4* w, const f32x4* x, size_t xmask, f32x4* y, size_t ymask, float* out,
+                unsigned long long* cyc, int wgs) {
+  const int ntiles = 40, wchunks = 20;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((probe<WPC, XPC, SPT, MF, LR, NCH>), dim3(wgs), dim3(512), 0, 0, w, wchunks, x, xmask, y, ymask, ntiles, out, cyc);
+  hipEventRecord(e0);
+  const int reps = 3;
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL((probe<WPC, XPC, SPT, MF, LR, NCH>), dim3(wgs), dim3(512), 0, 0, w, wchunks, x, xmask, y, ymask, ntiles, out, cyc);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long hc[1024];
+  hipMemcpy(hc, cyc, sizeof(unsigned long long) * wgs, hipMemcpyDeviceToHost);
+  double cs = 0;
+  for (int i = 0; i < wgs; ++i) cs += (double)hc[i];
+  cs /= wgs;
+  const double us_tile = ms * 1e3 / reps / ntiles;
+  const double kib_tile = NCH * (WPC * 8.0 + XPC * 8.0) + SPT * 8.0;     // per workgroup
+  printf("%-44s wgs %4d: %7.2f us/tile  %8.0f clk/tile  %6.1f B/clk/CU  (w %4.0f x %4.0f st %4.0f KiB/tile)  chip %6.2f TB/s hbm-side %6.2f TB/s\n",
+         name, wgs, us_tile, cs / ntiles, kib_tile * 1024 / (cs / ntiles), NCH * WPC * 8.0, NCH * XPC * 8.0, SPT * 8.0,
+         kib_tile * 1024 * wgs / us_tile / 1e6, (NCH * XPC * 8.0 + SPT * 8.0) * 1024 * wgs / us_tile / 1e6);
+}
+
+int main() {
+  const size_t xbytes = 4ull << 30, ybytes = 4ull << 30;
+  f32x4 *w, *x, *y;
+  float* out;
+  unsigned long long* cyc;
+  hipMalloc(&w, 1 << 20); hipMalloc(&x, xbytes); hipMalloc(&y, ybytes); hipMalloc(&out, 4); hipMalloc(&cyc, 8 * 1024);
+  hipMemset(w, 0, 1 << 20); hipMemset(x, 0, xbytes);
+  const size_t xmask = xbytes / 16 - 1 - 63, ymask = ybytes / 16 - 1 - 63;   // keeps 64-piece alignment
+  for (int wgs : {256}) {
+    run<2, 0, 0, 0, 0, 20>("W only (L2 stream, 16 KiB/chunk)", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<2, 0, 0, 0, 1, 20>("W + LDS fragment reads", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<0, 2, 0, 0, 0, 20>("X only (HBM stream, 16 KiB/chunk)", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<0, 3, 0, 0, 0, 20>("X only, 24 KiB/chunk", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<2, 2, 0, 0, 0, 20>("W + X", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<2, 2, 0, 24, 1, 20>("W + X + LDS + 24 MFMA", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<0, 0, 0, 24, 0, 20>("24 MFMA only", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<0, 2, 48, 0, 0, 20>("X + stores (48 KiB/wave/tile)", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<2, 2, 48, 0, 0, 20>("W + X + stores", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<2, 2, 48, 24, 1, 20>("W + X + stores + LDS + 24 MFMA (skeleton)", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<2, 2, 32, 24, 1, 20>("skeleton, no sigmoid store", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<2, 3, 48, 24, 1, 20>("skeleton + residual re-read", w, x, xmask, y, ymask, out, cyc, wgs);
+    run<1, 2, 48, 24, 1, 20>("skeleton, half the weights (512 rows/pass)", w, x, xmask, y, ymask, out, cyc, wgs);
+  }
+  return 0;
+}

@@ -131,6 +131,22 @@ __device__ __forceinline__ void wn_absmax_publish_any(float* slot, float v) {
     atomicMax(reinterpret_cast<int*>(slot), __float_as_int(v));
 }
 
+// max over |.| taken on the bit patterns: NaN (0x7fc00000) > inf > every finite value, so unlike fmaxf a NaN or an inf among
+// the operands is never dropped (wmax >= 0 always, so its own bits order the same way)
+__device__ __forceinline__ float wn_absmax_acc(float wmax, float a, float b, float c, float d) {
+  const unsigned m0 = max(__float_as_uint(a) & 0x7fffffffu, __float_as_uint(b) & 0x7fffffffu);
+  const unsigned m1 = max(__float_as_uint(c) & 0x7fffffffu, __float_as_uint(d) & 0x7fffffffu);
+  return __uint_as_float(max(__float_as_uint(wmax), max(m0, m1)));
+}
+// wave-wide form of the same maximum; non-finite results are clamped to 3e38 ("beyond any limit")
+__device__ __forceinline__ float wn_wave_absmax_bits(float wmax) {
+  unsigned m = __float_as_uint(wmax);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  const float v = __uint_as_float(m);
+  return v < 3.0e38f ? v : 3.0e38f;
+}
+
 // forward activations at or beyond this magnitude trip the range guard of the split-precision mode (fp16 max 65504)
 #define WN_RANGE_LIMIT 30000.0f
 

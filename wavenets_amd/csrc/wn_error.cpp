@@ -25,7 +25,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //    8  = 1: per-block weight gradients on the generic job table (no wn_wgrad_layer_kernel)
 //    9  = 1: no side stream in the weight-gradient phase
 //   10  > 0: time splits per utterance of the weight-gradient slabs
-//   11  =1: no composed split-precision forward for blocks too wide for the one-kernel forward (R = D = 128)
+//   11  = 1: 128-channel blocks on the exact-fp32 one-kernel forward; = 2: on the two split-precision contractions
+//       (gated conv + gate, 1x1 + residual) instead of the streamed-weights one-kernel forward (wn_layer16s.hip)
 //   12  = 1: no 256-column wide streamed kernel (N = 256 contractions as two 128-column blocks)
 //   13  = 1: 128-channel per-block weight gradients on the generic job table (no wn_wgrad_pair_kernel)
 //   14  = 1: global conditioning per block (no single contraction over all blocks)

@@ -184,7 +184,7 @@ __device__ __forceinline__ void wn_g16_epilogue(const WnGemmArgs& a, f32x16 (&ac
                   v[2] = wn_gate_bwd_g(v[2], gv.z, zv.z); v[3] = wn_gate_bwd_g(v[3], gv.w, zv.w);
                 }
               }
-              wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+              wmax = wn_absmax_acc(wmax, v[0], v[1], v[2], v[3]);
             }
             outv[jj][4 * rq + 0] = v[0]; outv[jj][4 * rq + 1] = v[1];
             outv[jj][4 * rq + 2] = v[2]; outv[jj][4 * rq + 3] = v[3];
@@ -398,9 +398,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_kernel(WnGemmArgs a, co
     if (live) wn_g16_epilogue<JT, PITCH, 0, EPI>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
   }
   if (absmax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+    wmax = wn_wave_absmax_bits(wmax);
+    if (lane == 0) { if (a.absmax_any) wn_absmax_publish_any(absmax_out, wmax); else wn_absmax_publish(absmax_out, wmax); }
   }
 }
 
@@ -563,9 +562,8 @@ __global__ __launch_bounds__(512, 1) void wn_gemm_rows16_wide_kernel(WnGemmArgs 
     if (live) wn_g16_epilogue<JT, PITCH, 0, EPI>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
   }
   if (absmax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+    wmax = wn_wave_absmax_bits(wmax);
+    if (lane == 0) { if (a.absmax_any) wn_absmax_publish_any(absmax_out, wmax); else wn_absmax_publish(absmax_out, wmax); }
   }
 }
 
@@ -677,9 +675,8 @@ __global__ __launch_bounds__(64) void wn_gemm_rows16_thin_kernel(WnGemmArgs a, c
   float wmax = 0.f;
   wn_g16_epilogue<1, PITCH>(a, acc, inv_sc, jb, b, t, row0, rows_valid, stage, lane, wmax);
   if (absmax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+    wmax = wn_wave_absmax_bits(wmax);
+    if (lane == 0) { if (a.absmax_any) wn_absmax_publish_any(absmax_out, wmax); else wn_absmax_publish(absmax_out, wmax); }
   }
 }
 
@@ -831,9 +828,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
     if (has_next) cur = nxt;
   }
   if (absmax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-    if (lane == 0) wn_absmax_publish(absmax_out, wmax);
+    wmax = wn_wave_absmax_bits(wmax);
+    if (lane == 0) { if (a.absmax_any) wn_absmax_publish_any(absmax_out, wmax); else wn_absmax_publish(absmax_out, wmax); }
   }
 }
 

@@ -61,6 +61,7 @@ struct WnGemmArgs {
   int32_t vec_out;        // 1: y/addc/aux rows 16-byte aligned, N % 4 == 0
   float* y2;              // WN_EPI_GATE_FWD: the sigmoid [rows][ld_y2], or null (inference)
   int32_t ld_y2;
+  int32_t absmax_any;     // 1: absmax_out is a forward range-guard slot (records inf / NaN too), 0: a gradient's scale slot
 };
 int wn_launch_gemm_rows(const WnGemmArgs& a, hipStream_t s);
 // split-precision variant: w16 = ONE fp16 hi|lo image of all segments' weights concatenated along k
@@ -166,6 +167,10 @@ int wn_layer_fwd_supported(int R, int D, int KS);
 int wn_layer_fwd_f16_supported(int R, int D, int KS);
 int wn_launch_layer_fwd_f16(const WnLayerFwdArgs& a, hipStream_t s);
 size_t wn_frag16_floats(int I, int KK);
+// streamed-weights form for blocks too wide for LDS-resident images (R = D = 128; wn_layer16s.hip): frag_d = kind-1 image
+// A[2D][KS*R] in natural row-tile order, frag_r = kind-1 image A[R][D]
+int wn_layer_fwd_s128_supported(int R, int D, int KS);
+int wn_launch_layer_fwd_s128(const WnLayerFwdArgs& a, hipStream_t s);
 int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fused generation step (wn_gen.hip)

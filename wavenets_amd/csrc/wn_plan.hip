@@ -48,6 +48,7 @@ struct BlockInfo {
   int64_t g16u = -1;    // fp16 split image [W_r | W_s] (backward: d z) or -1
   int64_t g16r = -1;    // fp16 split image [W_r] alone (used with the precomputed W_s g_skip slice) or -1
   int64_t f16gate = -1; // fp16 split image of the gated conv with row tiles ordered [f f g g] per 64 channels, or -1
+  int64_t f16nat = -1;  // fp16 split image of the gated conv in natural row-tile order for the streamed one-kernel forward (R = D = 128), or -1
   int64_t g16uf = -1;   // fp16 split image [W_r | V(b)], V(b) = W_s(b) W_f0 (skip path folded into the first head conv), or -1
 };
 
@@ -320,7 +321,9 @@ int count_jobs(const wn_plan* p) {
 // (fold_F0 > 0: depth-1 blocks with skip convs feeding a head whose first conv is narrower than the skip width) and the
 // split-precision kernels run; knob 21 = 1 keeps the reference's two-step form (skip sum, then the head conv).
 bool fold_ok(const wn_plan* p) {
-  return p->fold_F0 > 0 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(21) != 1 && wn_debug_get(4) != 1;
+  // (knob 15 = 1 drops the last block's zero output gradient; the folded g_u product has no one-segment form without it)
+  return p->fold_F0 > 0 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(21) != 1 && wn_debug_get(4) != 1 &&
+         wn_debug_get(15) != 1;
 }
 
 // the head layers' weight gradients run as staged pair jobs when every final layer has a pair kind (widths 128 / 256)
@@ -492,6 +495,8 @@ struct Gemm {
   // split-precision image of ALL segments (concatenated along k); optional max-abs scalars
   Gemm& w16(const float* img) { w16_ = img; return *this; }
   Gemm& absmax(const float* in0, const float* in1, float* out) { am0_ = in0; am1_ = in1; amo_ = out; return *this; }
+  // forward range-guard slot: unlike a gradient's scale slot it must also record inf / NaN
+  Gemm& absmax_fwd(float* out) { amo_ = out; a.absmax_any = out ? 1 : 0; return *this; }
   Gemm(int B, int T, int N, int JTtot) {
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.N = N; a.JTtot = JTtot; a.act = WN_ACT_LINEAR; a.epi = WN_EPI_PLAIN;
@@ -600,6 +605,7 @@ struct BlockPtrs {
   const float* G16r;                      // [W_r] alone
   const float* G16uf;                     // [W_r | V(b)]: skip path folded into the first head conv (training), or null
   const float* F16g;                      // gated conv, row tiles [f f g g] per 64 channels (composed split-precision forward), or null
+  const float* F16n;                      // gated conv, natural row-tile order, for the streamed one-kernel forward (R = D = 128), or null
 };
 
 struct BlockBufs {
@@ -630,8 +636,23 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     h = f.P[i]; hc = k.D;
   }
   const int li = k.depth - 1;
-  // blocks too wide for the split-precision one-kernel forward: [gated conv + gate] -> [1x1 + residual] as two
-  // split-precision contractions, ahead of the exact-fp32 one-kernel forward   (knob 11 = 1 disables it)
+  // blocks too wide for LDS-resident weights (R = D = 128): one kernel that streams the fp16 hi|lo images through an LDS
+  // ring and keeps u and z on chip (wn_layer16s.hip); knob 11 = 2 -> the two-contraction form below, = 1 -> exact fp32
+  if (k.F16n && k.F16r && k.depth == 1 && k.Cc == 0 && hc == k.R && k.Cin == k.R && f.ldz % 4 == 0 && wn_debug_get(1) != 1 &&
+      wn_debug_get(11) == 0 && wn_layer_fwd_s128_supported(k.R, k.D, k.KS) && (int64_t)rows * k.R * 4 < ((int64_t)1 << 32)) {
+    WnLayerFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = h; a.frag_d = k.F16n; a.frag_r = k.F16r;
+    a.bias_d = k.bd[li]; a.bias_r = k.br; a.cb = k.cb;
+    a.x_out = f.x_out; a.o_out = f.O; a.z_out = f.Z; a.ldz = f.ldz; a.ag_out = f.AG;
+    a.res = f.res;                                      // (null: the residual is the conv input itself)
+    a.xt[0] = f.xt[0]; a.xt[1] = f.xt[1]; a.xt[2] = nullptr;
+    a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
+    a.absmax_out = f.fwd_absmax;
+    return wn_launch_layer_fwd_s128(a, s);
+  }
+  // the same blocks as [gated conv + gate] -> [1x1 + residual], two split-precision contractions, ahead of the exact-fp32
+  // one-kernel forward   (knob 11 = 1 disables it)
   if (k.F16g && k.F16r && k.Cc == 0 && !k.cb && !f.O && hc == k.R && f.ldz % 4 == 0 && wn_debug_get(1) != 1 &&
       wn_debug_get(11) != 1) {
     Gemm g(k.B, k.T, 2 * k.D, ceil32(2 * k.D));
@@ -644,7 +665,7 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     Gemm r(k.B, k.T, k.R, ceil32(k.R));
     r.seg(f.Z, f.ldz, k.D, 0, k.Fr).bias(k.br).w16(k.F16r);
     if (k.residual) r.addc(f.res ? f.res : f.x, k.Cin);
-    if (f.fwd_absmax) r.absmax(nullptr, nullptr, f.fwd_absmax);
+    if (f.fwd_absmax) r.absmax_fwd(f.fwd_absmax);
     return r.run(f.x_out, k.R, s);
   }
   if (k.fused && k.Cc == 0 && hc == k.R) {
@@ -980,6 +1001,13 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
             add_piece16(p, bi.f16gate, 64, p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D + half * p->D + 64 * q,
                         p->R, 2 * p->D, 1, t * (p->R / 16), 4 * q + 2 * half, 2 * p->D / 32);
       add_image16(p, bi.conv1);
+      // the streamed-weights one-kernel forward (wn_layer16s.hip) reads the conv's image in natural row-tile order
+      if (wn_layer_fwd_s128_supported(p->R, p->D, p->KS)) {
+        bi.f16nat = new_image16(p, 2 * p->D, p->KS * p->R);
+        for (int t = 0; t < p->KS; ++t)
+          add_piece16(p, bi.f16nat, 2 * p->D, p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D, p->R, 2 * p->D, 1,
+                      t * (p->R / 16));
+      }
     }
   // split-precision images of the generic contractions (each only when its shape qualifies:
   // K multiple of 16, N multiple of 32 and >= 64; otherwise the fp32-MFMA kernel runs)
@@ -1245,6 +1273,7 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   k.fused = p->fused_ok;
   if (p->fused16_ok && p->LPB == 1) { k.F16d = fragbase + bi.dil.back().frag16; k.F16r = fragbase + bi.conv1.frag16; }
   if (bi.f16gate >= 0) { k.F16g = fragbase + bi.f16gate; k.F16r = fragbase + bi.conv1.frag16; }
+  if (bi.f16nat >= 0) k.F16n = fragbase + bi.f16nat;
   if (bi.g16u >= 0) k.G16u = fragbase + bi.g16u;
   if (bi.g16r >= 0) k.G16r = fragbase + bi.g16r;
   if (bi.g16uf >= 0) k.G16uf = fragbase + bi.g16uf;
@@ -1438,7 +1467,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     // a = act(sum_b V(b)^T z_b + b'): the skip sum and the head's first conv in ONE contraction with F0 output columns
     const ConvInfo& c0 = p->finals[0];
     rc = Gemm(B, T, c0.cout, ceil32(c0.cout)).seg_planes(ws + L.Z, p->Dp, rows * p->Dp, p->N * p->Dp, nullptr)
-             .w16(fragbase + p->frag16_foldF).bias(ws + L.bfold).act(p->c.activation).absmax(nullptr, nullptr, fam)
+             .w16(fragbase + p->frag16_foldF).bias(ws + L.bfold).act(p->c.activation).absmax_fwd(fam)
              .run(ws + L.HA[0], c0.cout, s);
     if (rc) return rc;
     hin = ws + L.HA[0];
@@ -1446,7 +1475,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   } else if (p->c.use_skip) {
     rc = Gemm(B, T, p->Sh, ceil32(p->Sh)).seg_planes(ws + L.Z, p->Dp, rows * p->Dp, p->N * p->Dp, fragbase + p->frag_skipF)
              .w16(p->frag16_skipF >= 0 ? fragbase + p->frag16_skipF : nullptr)
-             .bias(ws + L.bias_sum).absmax(nullptr, nullptr, fam).run(ws + L.skipsum, p->Sh, s);
+             .bias(ws + L.bias_sum).absmax_fwd(fam).run(ws + L.skipsum, p->Sh, s);
     if (rc) return rc;
     hin = ws + L.skipsum;
   } else {
@@ -1462,7 +1491,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = Gemm(B, T, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
              .w16(c.frag16 >= 0 ? fragbase + c.frag16 : nullptr)
              .bias(params + p->tensors[c.bias_t].off).act(last ? WN_ACT_LINEAR : p->c.activation)
-             .absmax(nullptr, nullptr, last ? nullptr : fam).run(dst, c.cout, s);
+             .absmax_fwd(last ? nullptr : fam).run(dst, c.cout, s);
     if (rc) return rc;
     hin = dst; hc = c.cout;
   }
@@ -1811,7 +1840,9 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
     if (rc) return rc;
   }
-  rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT, wn_debug_get(1) != 1, loss_out + 2, s);
+  // (with dropout the split kernels read H * mask / (1 - rate) while only H is published: compare against limit * (1 - rate))
+  rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT * (p->drop_rate > 0.f ? 1.f - p->drop_rate : 1.f),
+                            wn_debug_get(1) != 1, loss_out + 2, s);
   if (rc) return rc;
   if (p->phase_on) (void)hipEventRecord(p->phase_ev[2], s);
   }
@@ -2637,7 +2668,7 @@ int layer_layout(const wn_layer_desc* d, int B, int T, LayerLayout& L) {
   L.Bc = cv.take(Cc > 0 ? (int64_t)wn_frag_floats(Cc, 2 * D) : 0);
   L.F16d = L.F16r = -1;
   if (d->depth == 1 && Cc == 0 && cin == 2 * D && (d->in_channels > 0 ? d->in_channels : R) == R &&
-      wn_layer_fwd_supported(R, D, KS) && wn_layer_fwd_f16_supported(R, D, KS)) {
+      ((wn_layer_fwd_supported(R, D, KS) && wn_layer_fwd_f16_supported(R, D, KS)) || wn_layer_fwd_s128_supported(R, D, KS))) {
     L.F16d = cv.take((int64_t)wn_frag16_floats(2 * D, KS * R));
     L.F16r = cv.take((int64_t)wn_frag16_floats(R, D));
   }
@@ -2728,7 +2759,11 @@ void layer_ptrs(const wn_layer_desc* d, const LayerLayout& L, const float* param
   k.Cc = d->cond_channels; k.cond = cond; k.cb = nullptr;
   if (k.Cc > 0) { k.Fc = ws + L.Fc; k.Bc = ws + L.Bc; k.bc = params + L.bc; k.bd[d->depth - 1] = ws + L.bias_u; }
   k.fused = wn_layer_fwd_supported(R, D, d->kernel_size) != 0;
-  if (L.F16d >= 0) { k.F16d = ws + L.F16d; k.F16r = ws + L.F16r; }
+  if (L.F16d >= 0) {
+    // (the natural-order image serves the LDS-resident kernel or, for 128 channels, the streamed one)
+    if (wn_layer_fwd_f16_supported(R, D, d->kernel_size)) k.F16d = ws + L.F16d; else k.F16n = ws + L.F16d;
+    k.F16r = ws + L.F16r;
+  }
 }
 
 }  // namespace

@@ -12,10 +12,13 @@ file name:
       causal/vars/{0,1}
       wavenet_blocks/wave_net_layer[_b]/dilated_stack/conv1d[_i]/vars/{0,1}
       wavenet_blocks/wave_net_layer[_b]/{conv1,conv_skip,conv_cond}/vars/{0,1}
-      final/conv1d[_i]/vars/{0,1}            mapping/dense[_j]/vars/{0,1}
+      final/conv1d[_i]/vars/{0,1}            mapping/layers/dense[_j]/vars/{0,1}
+  (``mapping`` is a ``keras.Sequential``, src/model.py:142-148: saving_lib keeps a Sequential's children under an extra
+  ``layers`` group; the trailing ``Identity`` layer has no variables)
   written and read by ``wavenets_amd/h5.py`` (no h5py in the image).  Weights only, like the reference.  The importer
-  identifies list members by their numeric suffix, not by the exact spelling of the class name, and ignores groups it does
-  not know (metrics, empty ``vars`` groups).  TensorFlow / Keras are not installed here, so this layout is derived from the
+  identifies list members by their numeric suffix, not by the exact spelling of the class name, ignores groups it does
+  not know (metrics, seed generators, empty ``vars`` groups) and accepts the mapping network with or without the
+  ``layers`` level.  TensorFlow / Keras are not installed here, so this layout is derived from the
   Keras 3 sources' description, not validated against a file Keras wrote.
 """
 from __future__ import annotations
@@ -53,7 +56,7 @@ def keras_path(var_name: str) -> str:
   elif head.startswith('final'):
     path = ['final', _suffix('conv1d', int(head[5:]))]
   elif head.startswith('mapping'):
-    path = ['mapping', _suffix('dense', int(head[7:]))]
+    path = ['mapping', 'layers', _suffix('dense', int(head[7:]))]
   else:
     raise ValueError(f'unknown variable {var_name}')
   return '/'.join(path + ['vars', idx])
@@ -65,6 +68,11 @@ def _members(group: dict):
     m = re.search(r'_(\d+)$', n)
     return int(m.group(1)) if m else 0
   return [group[n] for n in sorted((n for n in group if isinstance(group[n], dict)), key=key)]
+
+
+def _with_vars(members):
+  """Only the members that own variables (a Sequential also lists Identity / Dropout children)."""
+  return [g for g in members if isinstance(g.get('vars'), dict) and len(g['vars']) > 0]
 
 
 def _tree_from_model(model) -> dict:
@@ -87,7 +95,10 @@ def _weights_from_tree(model, tree: dict):
       raise ValueError('checkpoint variables do not match the model (different architecture?)')
   blocks = _members(tree.get('wavenet_blocks', {}))
   finals = _members(tree.get('final', {}))
-  mapping = _members(tree.get('mapping', {}))
+  mapping_group = tree.get('mapping', {})
+  if isinstance(mapping_group.get('layers'), dict):        # keras.Sequential: children live under 'layers'
+    mapping_group = mapping_group['layers']
+  mapping = _with_vars(_members(mapping_group))
   out = []
   for name in model.variable_names:
     parts = name.split('/')

@@ -133,7 +133,9 @@ class WaveNet(torch.nn.Module):
     self.loss_tracker = _Mean('loss')
     self.reg_loss = _Mean('reg_loss') if self.regularization else None
     self._sample_calls = 0
-    self.early_logs = True                # one replica: train_step reads its scalars back between forward and backward
+    # None = automatic: a single replica reads its step scalars back between forward and backward; data-parallel replicas
+    # take them from the gradient bucket's tail after the ONE all-reduce of the step (no second collective per step)
+    self.early_logs = None
     self._log_mirror, self._log_event = None, None
     self._drop_step = 0                   # training calls made so far (dropout mask counter; saved by io.save_weights)
     self._fused_step_sample = True        # train_step draws its metric sample inside the library
@@ -403,7 +405,9 @@ class WaveNet(torch.nn.Module):
     L = _lib.lib()
     slot = L.wn_plan_range_slot(self._plan, B, T, int(training))
     m = float(ws[slot])
-    return not (m < L.wn_range_limit())
+    # with dropout the split kernels read H * mask / (1 - rate) while H is what the slot records
+    limit = L.wn_range_limit() * ((1.0 - self.dropout) if (training and self.dropout > 0) else 1.0)
+    return not (m < limit)
 
   def set_drop_step(self, n: int):
     """Training calls already made (resume): the next dropout mask is that of call n + 1."""
@@ -506,7 +510,8 @@ class WaveNet(torch.nn.Module):
   def _train_step_once(self, data):
     want_metric = len(self._metrics_from_compilation) > 0
     from . import dp
-    if self.early_logs:
+    early = self.early_logs if self.early_logs is not None else self._world() == 1
+    if early:
       # loss, reg_loss, the range flag and the sample metrics are final right after the loss kernels.  Their device-to-host
       # copy is queued THERE, between the forward and the backward half of the step, and the host waits for that copy
       # only -- it returns with 4 ms of the step still queued and has the next step's launches out before the GPU runs
