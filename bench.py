@@ -59,6 +59,7 @@ def parse_args(argv=None):
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-strong-leg', action='store_true', help='skip the extra global-batch-64 measurement')
   ap.add_argument('--no-generation', action='store_true', help='skip the generation-speed leg (N = 1 only)')
+  ap.add_argument('--no-other-configs', action='store_true', help='skip the other BASELINE configs (N = 1 only)')
   ap.add_argument('--cpu-budget', type=float, default=20.0)
   return ap.parse_args(argv)
 
@@ -112,6 +113,61 @@ def generation_leg(dev, B: int = 8, n: int = 1000):
       ts.append(best)
     per = (ts[1] - ts[0]) / (steps - steps // 4)
     res[name] = {'ms_per_sample_step': per * 1e3, 'samples_per_s_per_utterance': 1.0 / per, 'samples_per_s_aggregate': B / per}
+  return res
+
+
+# the other BASELINE.json configurations at their full size on one GPU (SURVEY.md 8(d) "Config -> constructor args")
+OTHER_CONFIGS = {
+    'configs[0]': (dict(blocks=10, channels=32, dilation_bound=1024, final_layers_channels=[], bits=8), 1,
+                   '10-layer mu-law-256, dilations 1..512, 32 residual ch, head [], batch 1x16000'),
+    'configs[3]': (dict(blocks=30, channels=128, skip_channels=256, dilation_bound=1024, final_layers_channels=[128, 256],
+                        activation='leaky_relu', num_mixtures=10, sampling_function='logistic', bits=16), 8,
+                   '30-layer mixture-of-logistics head (10 mixtures), 128 residual / 256 skip ch, batch 8x16000 per GPU'),
+    'configs[4]': (dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024, final_layers_channels=[128, 256],
+                        activation='leaky_relu', bits=8, conditioning='global', mapping_layers=[8, 16, 32],
+                        mapping_activation='leaky_relu'), 8,
+                   'global-conditioned (110-way one-hot speaker id, mapping [8,16,32]), 30 layers, batch 8x16000 per GPU'),
+}
+
+
+def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmup: int = 3):
+  """Train-step time and SURVEY 8(d) stack fraction of BASELINE configs[0], [3], [4] on one GPU (same step as the
+  headline: Adam + clipnorm + the MSE metric's sample draw).  Host-timed between two device synchronisations."""
+  import torch
+  from wavenets_amd import WaveNet, Adam, MeanSquaredError
+  from wavenets_amd.data import synthetic_waveforms
+  res = {}
+  for name, (kw, B, desc) in OTHER_CONFIGS.items():
+    m = WaveNet(**kw, device=dev, seed=0)
+    m.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0), metrics=[MeanSquaredError()])
+    x = synthetic_waveforms(B, T + 1, seed=99, device=dev)
+    data = x
+    if kw.get('conditioning'):
+      spk = torch.randint(0, 110, (B,), generator=torch.Generator().manual_seed(1))
+      data = (x, torch.nn.functional.one_hot(spk, 110).float().to(dev))
+    for _ in range(warmup):
+      logs = m.train_step(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      logs = m.train_step(data)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nblk = kw['blocks']
+    _, avg_ms, n_s, stack_ms, prep_ms = stack_profile(m, data, 5, nblk)
+    R = kw['channels']
+    S_eff = kw.get('skip_channels') or R
+    stack_bytes = nblk * 4.0 * B * T * (2 * R + S_eff)
+    t_stack = stack_ms + prep_ms
+    res[name] = {'workload': desc, 'ms_per_step': dt * 1e3, 'samples_per_s': B * T / dt, 'steps': steps,
+                 'final_loss': logs['loss'],
+                 'stack_fwd': {'t_stack_fwd_ms': t_stack, 't_fold_prep_ms': prep_ms, 'passes_timed': n_s,
+                               'algorithmic_bytes': stack_bytes,
+                               'achieved_GBps': stack_bytes / (t_stack * 1e-3) / 1e9 if t_stack > 0 else None,
+                               'frac': stack_bytes / (t_stack * 1e-3) / 1e9 / HBM_PEAK_GBS if t_stack > 0 else None,
+                               'block_launch_avg_ms': avg_ms}}
+    del m
+    torch.cuda.empty_cache()
   return res
 
 
@@ -227,19 +283,35 @@ def main():
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item()), per, logs
 
+  def stack_profile(m, data, steps, nblocks):
+    """(block launches timed, avg ms per launch, stack passes timed, avg stack ms, avg fold-prep ms) over `steps`
+    extra training steps with the library's event hooks armed."""
+    _lib.check(L.wn_prof_enable(m._plan, nblocks * steps))
+    _lib.check(L.wn_stack_prof_enable(m._plan, steps))
+    for _ in range(steps):
+      m.train_step(data)
+    torch.cuda.synchronize()
+    nl, av = C.c_int32(), C.c_float()
+    _lib.check(L.wn_prof_read(m._plan, C.byref(nl), C.byref(av)))
+    _lib.check(L.wn_prof_enable(m._plan, 0))
+    npp, pm = C.c_int32(), C.c_float()
+    _lib.check(L.wn_stack_prof_read_foldprep(m._plan, C.byref(npp), C.byref(pm)))
+    ns_, sm = C.c_int32(), C.c_float()
+    _lib.check(L.wn_stack_prof_read(m._plan, C.byref(ns_), C.byref(sm)))
+    _lib.check(L.wn_stack_prof_enable(m._plan, 0))
+    return nl.value, av.value, ns_.value, sm.value, pm.value
+
   model = make_model()
   x = synthetic_waveforms(B, T + 1, seed=1234 + rank, device=dev)
-  for _ in range(args.warmup):
-    model.train_step(x)
-  _lib.check(L.wn_prof_enable(model._plan, nblk * min(args.steps, 20)))
-  _lib.check(L.wn_stack_prof_enable(model._plan, min(args.steps, 50)))
-  dt, per_step, logs = timed_steps(model, x, args.steps, 0)
-  n_l, avg_ms = C.c_int32(), C.c_float()
-  _lib.check(L.wn_prof_read(model._plan, C.byref(n_l), C.byref(avg_ms)))
-  _lib.check(L.wn_prof_enable(model._plan, 0))
-  n_s, stack_ms = C.c_int32(), C.c_float()
-  _lib.check(L.wn_stack_prof_read(model._plan, C.byref(n_s), C.byref(stack_ms)))
-  _lib.check(L.wn_stack_prof_enable(model._plan, 0))
+  # the timed region carries no measurement hooks: W warm-up steps, then exactly K steps between two barriers
+  dt, per_step, logs = timed_steps(model, x, args.steps, args.warmup)
+  # roofline inputs from EXTRA, untimed steps: HIP events on the launch stream around the block chain (per-launch
+  # average of the fused block kernel), around the whole stack (first block launch -> end of the folded contraction) and
+  # around the fold's per-pass weight-space preparation (V = W_s W_f0 and its fp16 images), which runs before the stack
+  n_prof = max(3, min(args.steps, 10))
+  n_l, avg_ms, n_s, stack_ms, prep_ms = stack_profile(model, x, n_prof, nblk)
+  if world > 1:
+    sync()
   ms_per_step = dt / args.steps * 1e3
   value = world * B * T * args.steps / dt
 
@@ -322,8 +394,10 @@ def main():
     R, S = CFG2['channels'], CFG2['skip_channels']
     bytes_layer = 4.0 * B * T * (2 * R + S)          # read x, write x_out, write skip
     stack_bytes = nblk * bytes_layer
-    achieved = stack_bytes / (stack_ms.value * 1e-3) / 1e9 if stack_ms.value > 0 else 0.0
-    kern_gbs = (traffic / (avg_ms.value * 1e-3) / 1e9) if (traffic and avg_ms.value > 0) else None
+    # t_stack_fwd INCLUDES the fold's weight-space preparation of the pass (it exists only because the skip path is folded)
+    t_stack = stack_ms + prep_ms
+    achieved = stack_bytes / (t_stack * 1e-3) / 1e9 if t_stack > 0 else 0.0
+    kern_gbs = (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None
     out = {
         'metric': 'audio samples/sec (training step, 16 kHz mu-law)',
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -348,17 +422,22 @@ def main():
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      'algorithmic_bytes_per_stack_pass': stack_bytes, 'algorithmic_bytes_per_block': bytes_layer,
-                     't_stack_fwd_ms': stack_ms.value, 'passes_timed': n_s.value,
-                     'fused_block_kernel': {'kernel': 'wn_layer_fwd_f16_kernel', 'avg_launch_ms': avg_ms.value,
-                                            'launches_timed': n_l.value, 'counter_bytes_per_launch': traffic,
+                     't_stack_fwd_ms': t_stack, 't_blocks_and_folded_contraction_ms': stack_ms, 't_fold_prep_ms': prep_ms,
+                     'passes_timed': n_s,
+                     'fused_block_kernel': {'kernel': 'wn_layer_fwd_f16_kernel', 'avg_launch_ms': avg_ms,
+                                            'launches_timed': n_l, 'counter_bytes_per_launch': traffic,
                                             'counter_GBps': kern_gbs,
                                             'counter_frac_of_peak': (kern_gbs / HBM_PEAK_GBS) if kern_gbs else None,
                                             'mfma_busy_per_wave_cycle': mfma_busy},
-                     'note': 'traffic = HBM bytes per launch of the fused block kernel (profiles/, FETCH x2 + WRITE); it '
-                             'writes x_out, z and the saved sigmoid -- the skip tensors of the algorithmic signature are '
-                             'consumed inside the folded contraction, which is part of the timed stack (and, folded with '
-                             "the head's first conv, does more than the 8(d) stack asks for)"},
+                     'note': 'measured in extra untimed steps after the timed region; traffic = HBM bytes per launch of the '
+                             'fused block kernel (profiles/, FETCH x2 + WRITE); it writes x_out, z and the saved sigmoid -- '
+                             'the skip tensors of the algorithmic signature are consumed inside the folded contraction, which '
+                             "is part of the timed stack, as is the fold's per-pass weight preparation"},
     }
+    if world == 1 and not args.no_other_configs:
+      del model
+      torch.cuda.empty_cache()
+      out['other_configs'] = other_configs_leg(dev, stack_profile)
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args.cpu_budget)
     if world == 1 and not args.no_generation:

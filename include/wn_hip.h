@@ -119,6 +119,9 @@ int wn_debug_ws_region(const wn_plan* p, int32_t B, int32_t T, int32_t what, int
  * the end of the folded skip contraction = t_stack_fwd of SURVEY.md 8(d); read returns passes and the average */
 int wn_stack_prof_enable(wn_plan* p, int32_t max_passes);
 int wn_stack_prof_read(wn_plan* p, int32_t* passes, float* avg_ms);
+/* the per-pass weight-space preparation of the folded skip path of the same passes (bias sum, V = W_s W_f0, fp16 images;
+ * it runs before the first block launch, outside the pair above): average per pass, 0 when the plan does not fold */
+int wn_stack_prof_read_foldprep(wn_plan* p, int32_t* passes, float* avg_ms);
 /* phase marks of wn_train_fwd_bwd: ms4 = {forward, loss, backward-data chain, weight gradients + rest}
  * of the last call (read after a stream sync) */
 int wn_phase_enable(wn_plan* p, int32_t on);

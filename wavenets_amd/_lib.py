@@ -79,6 +79,7 @@ _SIGS = {
                                      C.POINTER(C.c_int64)]),
     'wn_stack_prof_enable': (C.c_int, [_P, C.c_int32]),
     'wn_stack_prof_read': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    'wn_stack_prof_read_foldprep': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     'wn_phase_enable': (C.c_int, [_P, C.c_int32]),
     'wn_phase_read': (C.c_int, [_P, C.POINTER(C.c_float)]),
     'wn_forward': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),

@@ -4,11 +4,11 @@
 // Same chain and register orientation as wn_layer16.hip -- time on lanes, u = b_d + sum_tap W_tap^T x[t - shift] ->
 // z = tanh * sigmoid -> o = b_r + W_r^T z -> x_out = o + x, every product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
 // v_mfma_f32_32x32x16_f16 -- but the fp16 hi|lo images of one block are 256 KiB (gated conv) + 64 KiB (1x1), twice the LDS.
-// So the workgroup (8 waves = 256 rows per pass) STREAMS them: the images are one sequence of 20 chunks of 16 KiB (16
-// k-steps of the conv with all 8 row tiles, then 4 x two k-steps of the 1x1) that cycles through a 4-deep LDS ring
-// filled by LDS-DMA, two chunks in flight, one raw barrier per chunk; the stream never stops at a tile boundary (the
-// weights do not depend on the tile).  The activations of a k-step come by LDS-DMA too (three k-steps in flight, into the
-// wave's otherwise idle output stage), so the only waits in the loop are counted s_waitcnt vmcnt(N).  u (32 x 256) stays
+// So a workgroup (4 waves = 128 rows per pass, two workgroups per CU) STREAMS them: the images are one sequence of 20
+// chunks of 16 KiB (16 k-steps of the conv with all 8 row tiles, then 4 x two k-steps of the 1x1) that cycles through a
+// 3-deep LDS ring filled by LDS-DMA, two chunks in flight, one raw barrier per chunk; the stream never stops at a tile
+// boundary (the weights do not depend on the tile).  The activations of a k-step come by LDS-DMA too (two k-steps in
+// flight, into the wave's otherwise idle output stage), so the only waits in the loop are counted s_waitcnt vmcnt(N).  u (32 x 256) stays
 // in 128 accumulator registers per lane, the gate runs in registers and z feeds the 1x1 as the B operand as it stands: u
 // never touches HBM and z is written once (for the folded skip contraction and backward), never read back here.
 //
@@ -56,51 +56,62 @@ struct G {
   static constexpr int NC1 = KS * R / 16;              // conv chunks (one k-step of 8 row tiles = 16 KiB each)
   static constexpr int NC2 = (D / 16) * R32 / 8;       // 1x1 chunks (two k-steps of 4 row tiles each)
   static constexpr int NCH = NC1 + NC2;
-  static constexpr int CHUNK = 16384, NBUF = 4, XB = 4, XBUF = 2048;
-  static constexpr int PITCH = 68, STAGE = 32 * PITCH * 4;          // 8704 >= XB * XBUF
-  static constexpr int WAVES = 8;
+  static constexpr int CHUNK = 16384, NBUF = 3, XB = 3, XBUF = 2048;
+  static constexpr int WAVES = 4, THREADS = 256;
+  static constexpr int PITCH = 36, STAGE = 32 * PITCH * 4;          // 4608: one 32 x 32 tile
+  static constexpr int REGION = XB * XBUF;                          // per wave: activation ring, reused as the output stage
   static constexpr int BIAS = (2 * D + R) * 4;
-  static constexpr int LDS = NBUF * CHUNK + WAVES * STAGE + BIAS;   // 136704
-  static constexpr int PT = CHUNK / 16 / 512;          // weight-DMA instructions per thread and chunk
+  static constexpr int LDS = NBUF * CHUNK + WAVES * REGION + BIAS;  // 75264: two workgroups per CU
+  static constexpr int PT = CHUNK / 16 / THREADS;      // weight-DMA instructions per thread and chunk (4)
   static constexpr int PX = 2;                         // activation-DMA instructions per lane and k-step
+  static_assert(STAGE <= REGION, "the output stage lives in the activation ring");
 };
 
-// 32 x 64 half tile (two D-layout accumulator tiles) -> wave-private LDS stage -> 256-byte row segments in HBM.
-// dst = wave-uniform base of the tile's first row (+ column offset), voff = this lane's byte offset inside a group of four
-// rows: the stores are scalar base + 32-bit lane offset (64-bit per-row addresses in VGPRs are what spills in the epilogue);
-// the read-back runs in two groups of four rows so that at most 16 data registers are in flight.
-template <int PITCH>
-__device__ __forceinline__ void store_half(const f32x16& v0, const f32x16& v1, float* stage, float* dst, unsigned voff,
-                                           unsigned ld_bytes, int rows_valid, int lane) {
+// one 32 x 32 D-layout accumulator tile -> wave-private LDS stage -> 128-byte row segments in HBM.
+// dst = wave-uniform address of the tile's first row (+ column offset), voff = this lane's byte offset inside a group of
+// eight rows: the stores are scalar base + 32-bit lane offset.  The base goes through an empty asm so that it stays ONE
+// scalar: otherwise hipcc re-associates (tensor + lane offset) + row, hoists that 64-bit VGPR pair of every output tensor
+// out of the tile loop, spills it, and reloads it with s_waitcnt vmcnt(0) in the middle of the stores.
+// FULL: all 32 rows exist (no per-row predicate, no branches).
+template <int PITCH, bool FULL, bool NOSTORE = false, bool ADD = false>
+__device__ __forceinline__ void store_tile(const f32x16& v, float* stage, float* dst, unsigned voff, unsigned ld_bytes,
+                                           int rows_valid, int lane, const f32x4* add = nullptr) {
   const int tl = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const f32x16& v = jj ? v1 : v0;
-      f32x4 o;
-      o.x = v[4 * rq + 0]; o.y = v[4 * rq + 1]; o.z = v[4 * rq + 2]; o.w = v[4 * rq + 3];
-      *reinterpret_cast<f32x4*>(stage + tl * PITCH + 32 * jj + 8 * rq + 4 * h) = o;
-    }
+  for (int rq = 0; rq < 4; ++rq) {
+    f32x4 o;
+    o.x = v[4 * rq + 0]; o.y = v[4 * rq + 1]; o.z = v[4 * rq + 2]; o.w = v[4 * rq + 3];
+    *reinterpret_cast<f32x4*>(stage + tl * PITCH + 8 * rq + 4 * h) = o;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const float* rd = stage + (lane >> 4) * PITCH + (lane & 15) * 4;
-  char* base = reinterpret_cast<char*>(dst);
+  const float* rd = stage + (lane >> 3) * PITCH + (lane & 7) * 4;
+  char* base0 = reinterpret_cast<char*>(dst);
+  asm volatile("" : "+s"(base0));
+  // (the asm drops the address space: restore it, or the stores become flat_store)
+  __attribute__((address_space(1))) char* base = (__attribute__((address_space(1))) char*)base0;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-#pragma unroll
-    for (int i = 4 * g; i < 4 * g + 4; ++i) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(rd + i * 4 * PITCH);
-      if (i * 4 + (lane >> 4) < rows_valid)
-        *reinterpret_cast<f32x4*>(base + (uint64_t)((unsigned)(i * 4) * ld_bytes) + voff) = o;
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < 4; ++i) {
+    f32x4 o = *reinterpret_cast<const f32x4*>(rd + i * 8 * PITCH);
+    if constexpr (ADD) { o.x += add[i].x; o.y += add[i].y; o.z += add[i].z; o.w += add[i].w; }
+    if (NOSTORE ? (o.x == 1.2345e-30f) : (FULL || i * 8 + (lane >> 3) < rows_valid))      // (NOSTORE: timing ablation)
+      *(__attribute__((address_space(1))) f32x4*)(base + (uint64_t)((unsigned)(i * 8) * ld_bytes) + voff) = o;
   }
   asm volatile("" ::: "memory");
 }
 
 // RESMODE 0: no residual; 1: x_out = o + (a.res ? a.res : a.x).  SAVE: the sigmoid is written for backward (training).
-template <int KS, int RESMODE, bool SAVE>
-__global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArgs a) {
+//
+// Two workgroups of FOUR waves per CU (75 KiB of LDS, <= 256 registers per lane each): a wave that stores and then waits
+// for a load waits for its stores too -- vmcnt is one in-order counter per wave -- so inside one workgroup the phases
+// load | gate | store | 1x1 | store run one after the other (first form of this kernel, 8 waves per CU: 100 us per launch
+// against 55 us for its bytes).  With two independent workgroups per CU one drains its stores while the other runs its
+// products.
+// DIAG != 0: timing ablations (knob 29; results are meaningless): 1 no global stores, 2 no activation requests, 4 no
+// products, 8 no gate transcendentals, 16 no residual loads, 32 no weight requests
+template <int KS, int RESMODE_, bool SAVE, int DIAG = 0>
+__global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArgs a) {
+  constexpr int RESMODE = (DIAG & 16) ? 0 : RESMODE_;
+  constexpr bool NOST = (DIAG & 1) != 0;
   using C = G<KS>;
   constexpr int R = C::R, D = C::D, NC1 = C::NC1, NCH = C::NCH, PITCH = C::PITCH, PT = C::PT, PX = C::PX;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
@@ -108,42 +119,40 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
   // the wave index through an SGPR: every LDS-DMA destination (M0) and every ring address is then scalar arithmetic
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl = lane & 31, h = lane >> 5;
-  float* stage = reinterpret_cast<float*>(smem + C::NBUF * C::CHUNK + wave * C::STAGE);
-  unsigned char* const xbuf = reinterpret_cast<unsigned char*>(stage);
+  unsigned char* const xbuf = smem + C::NBUF * C::CHUNK + wave * C::REGION;
+  float* stage = reinterpret_cast<float*>(xbuf);
   const unsigned smem_addr = lds_addr_of(smem), xbuf_addr = lds_addr_of(xbuf);
-  float* sbias = reinterpret_cast<float*>(smem + C::NBUF * C::CHUNK + C::WAVES * C::STAGE);
-  for (int i = tid; i < 2 * D; i += 512) sbias[i] = a.bias_d[i];
-  for (int i = tid; i < R; i += 512) sbias[2 * D + i] = a.bias_r[i];
+  float* sbias = reinterpret_cast<float*>(smem + C::NBUF * C::CHUNK + C::WAVES * C::REGION);
+  for (int i = tid; i < 2 * D; i += C::THREADS) sbias[i] = a.bias_d[i];
+  for (int i = tid; i < R; i += C::THREADS) sbias[2 * D + i] = a.bias_r[i];
   const float* lbias_d = sbias;
   const float* lbias_r = sbias + 2 * D;
 
   const int tiles_per_b = (a.T + 31) >> 5;
   const int64_t ntiles = (int64_t)a.B * tiles_per_b;
   const int64_t per_pass = (int64_t)gridDim.x * C::WAVES;
-  const int64_t passes = (ntiles + per_pass - 1) / per_pass;
+  const int passes = (int)((ntiles + per_pass - 1) / per_pass);
 
-  // weight chunk of stream position g (chunk g % NCH of the images) -> ring buffer g % NBUF; every wave instruction
-  // moves one contiguous KiB (wave-uniform LDS base + lane * 16)
-  // (source = scalar base + ONE 32-bit per-thread byte offset: 64-bit per-chunk addresses in VGPRs get hoisted out of the
-  // tile loop and spilled)
+  // weight chunk cc of the tile's sequence -> ring slot; piece i of a thread: 1 KiB per wave instruction
   const unsigned woff = (unsigned)tid * 16u;
-  auto wdma = [&](int cc, int slot) {                  // cc = chunk inside the tile's sequence, compile-time at every call
+  auto wpiece = [&](int cc, int slot, int i) {         // cc, i compile-time at every call; slot scalar
     const char* base = cc < NC1 ? reinterpret_cast<const char*>(a.frag_d) + (int64_t)cc * C::CHUNK
                                 : reinterpret_cast<const char*>(a.frag_r) + (int64_t)(cc - NC1) * C::CHUNK;
-#pragma unroll
-    for (int i = 0; i < PT; ++i) {
-      dma16(base + 8192 * i, woff, smem_addr + slot * C::CHUNK + (512 * i + wave * 64) * 16);
-    }
+    if constexpr (!(DIAG & 32)) dma16(base + 4096 * i, woff, smem_addr + slot * C::CHUNK + (C::THREADS * i + wave * 64) * 16);
   };
+  auto next_slot = [](int s) { return s + 1 == C::NBUF ? 0 : s + 1; };
 
   float wmax = 0.f;
   __syncthreads();                                     // bias table
   // the first two chunks of the stream
-  wdma(0, 0);
-  wdma(1, 1);
+#pragma unroll
+  for (int i = 0; i < PT; ++i) wpiece(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < PT; ++i) wpiece(1, 1, i);
+  int slot0 = 0;                                       // ring slot of the current tile's chunk 0 (scalar)
 
-  for (int64_t pass = 0; pass < passes; ++pass) {
-    const int64_t tile = (pass * gridDim.x + blockIdx.x) * C::WAVES + wave;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int64_t tile = ((int64_t)pass * gridDim.x + blockIdx.x) * C::WAVES + wave;
     const bool live = tile < ntiles;                   // dead waves still take part in the barriers and the weight stream
     const int b = live ? (int)(tile / tiles_per_b) : 0;
     const int t0 = live ? (int)(tile % tiles_per_b) * 32 : 0;
@@ -152,8 +161,8 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     const int rows_valid = live ? min(32, a.T - t0) : 0;
     const int64_t row0 = (int64_t)b * a.T + t0;
 
-    // per-tap source row of this lane (clamped; masked rows are zeroed at use)
-    // (32-bit byte offsets from a scalar base; the launcher checks that the tensors stay below 4 GiB)
+    // per-tap source row of this lane (clamped; masked rows are zeroed at use): 32-bit byte offsets from a scalar base
+    // (the launcher checks that the tensors stay below 4 GiB)
     unsigned xoff[KS];
     bool xok[KS];
 #pragma unroll
@@ -165,9 +174,11 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     auto xdma = [&](int c) {                           // activations of conv k-step c -> activation buffer c % XB
       const int tap = c / (R / 16), kk = c % (R / 16);
       const char* base = reinterpret_cast<const char*>(a.xt[tap] ? a.xt[tap] : a.x) + 64 * kk;
-      const unsigned dst = xbuf_addr + (c & (C::XB - 1)) * C::XBUF;  // wave-uniform
-      dma16(base, xoff[tap], dst);
-      dma16(base + 32, xoff[tap], dst + 1024);
+      const unsigned dst = xbuf_addr + (c % C::XB) * C::XBUF;       // wave-uniform
+      if constexpr (!(DIAG & 2)) {
+        dma16(base, xoff[tap], dst);
+        dma16(base + 32, xoff[tap], dst + 1024);
+      }
     };
 
     // ---- accumulators start at the bias (+ per-utterance conditioning bias) ----
@@ -189,27 +200,25 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
           u[j][4 * rq + 0] += cv.x; u[j][4 * rq + 1] += cv.y; u[j][4 * rq + 2] += cv.z; u[j][4 * rq + 3] += cv.w;
         }
     }
-    // Issue order per tile:  x0 x1 x2 | w(c+2) x(c+3) | ...   with w(0), w(1) of THIS tile issued during the previous
-    // tile's last two chunks (or before the loop).  vmcnt retires loads in order, so "at most N outstanding" with
-    // N = the LOADS issued after the ones chunk c needs means they have landed (stores in between only make the wait
-    // conservative: they never count as younger loads).
+
+    // Issue order per tile:  x0 x1 | step c: wait, barrier, then w(c+2) x(c+2) spread between the products of chunk c.
+    // (w(0), w(1) of THIS tile were requested during the previous tile's last two steps, or before the loop.)  Requests
+    // for chunk c + 2 go into the ring slot chunk c - 1 used, hence after the barrier every wave reaches once it has
+    // finished chunk c - 1.  vmcnt retires loads in order, so "at most N outstanding" with N = the LOADS issued after
+    // the ones chunk c needs means those have landed; stores in between only make the wait conservative.
     xdma(0);
     xdma(1);
-    xdma(2);
-    static_assert(NCH % C::NBUF == 0, "a tile's chunk sequence must start at ring slot 0");
-    constexpr int ring0 = 0;                             // NCH % NBUF == 0: every tile's chunk c lives in slot c % NBUF
+    int slot = slot0;                                  // ring slot of chunk c, advanced per step (scalar)
     // =================== dilated causal conv: NC1 chunks ===================
     wn_static_for<NC1>([&](auto cc_) {
       constexpr int c = decltype(cc_)::value;
-      wdma((c + 2) % NCH, (ring0 + c + 2) & (C::NBUF - 1));      // (past the tile's end: the next tile's first chunks)
-      if constexpr (c + 3 < NC1) xdma(c + 3);
-      // loads issued after w(c) / x(c):   [x(c+1) x(c+2)] w(c+1) w(c+2) [x(c+3)]  as far as they exist
-      constexpr int nx = (c + 1 < NC1) + (c + 2 < NC1) + (c + 3 < NC1);
-      constexpr int nw = c == 0 ? 1 : 2;               // at c == 0 the tile's w(0), w(1) are older than x(0)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nw * PT + nx * PX) : "memory");
+      // loads issued after x(c) [c <= 1: the prologue's] or after w(c), x(c) [step c - 2]:  w(c+1) x(c+1)
+      constexpr int nyl = c == 0 ? PX : PT + (c + 1 < NC1 ? PX : 0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nyl) : "memory");
       asm volatile("s_barrier" ::: "memory");
-      const h8* wl = reinterpret_cast<const h8*>(smem + ((ring0 + c) & (C::NBUF - 1)) * C::CHUNK) + lane;
-      const f32x4* xl = reinterpret_cast<const f32x4*>(xbuf + (c & (C::XB - 1)) * C::XBUF) + lane;
+      const int slot2 = next_slot(next_slot(slot));
+      const h8* wl = reinterpret_cast<const h8*>(smem + slot * C::CHUNK) + lane;
+      const f32x4* xl = reinterpret_cast<const f32x4*>(xbuf + (c % C::XB) * C::XBUF) + lane;
       constexpr int tap = c / (R / 16);
       f32x4 q0 = xl[0], q1 = xl[64];
       h8 fr[2][2];
@@ -224,12 +233,19 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
           fr[(j + 1) & 1][0] = wl[((j + 1) * 2 + 0) * 64];
           fr[(j + 1) & 1][1] = wl[((j + 1) * 2 + 1) * 64];
         }
-        u[j] = mfma16(fr[j & 1][1], bh, u[j]);
-        u[j] = mfma16(fr[j & 1][0], bl, u[j]);
-        u[j] = mfma16(fr[j & 1][0], bh, u[j]);
+        if constexpr (!(DIAG & 4)) {
+          u[j] = mfma16(fr[j & 1][1], bh, u[j]);
+          u[j] = mfma16(fr[j & 1][0], bl, u[j]);
+          u[j] = mfma16(fr[j & 1][0], bh, u[j]);
+        } else {
+          u[j][0] += (float)fr[j & 1][1][0] * (float)bh[0] + (float)fr[j & 1][0][1] * (float)bl[1];
+        }
+        // one request of the look-ahead chunk per product block (a request costs the wave ~100 clocks of issue)
+        if constexpr (j < PT) wpiece((c + 2) % NCH, slot2, j);
+        if constexpr (j == PT && c + 2 < NC1) xdma(c + 2);
         __builtin_amdgcn_sched_barrier(0);
       });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this chunk's buffers are free again
+      slot = next_slot(slot);
     });
 
     // =================== gate (in place): u[j] -> z, u[j + 4] -> sigmoid ===================
@@ -237,37 +253,52 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     for (int j = 0; j < C::D32; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float sg = wn_sigmoid_fast(u[j + C::D32][r]);
+        const float sg = (DIAG & 8) ? u[j + C::D32][r] * 0.5f : wn_sigmoid_fast(u[j + C::D32][r]);
         u[j + C::D32][r] = sg;
-        u[j][r] = wn_tanh_fast(u[j][r]) * sg;
+        u[j][r] = ((DIAG & 8) ? u[j][r] : wn_tanh_fast(u[j][r])) * sg;
       }
-    // lane offset inside a group of four rows (row stride 512 B for the R / D wide tensors, ldz * 4 for z)
-    const unsigned voff128 = (unsigned)(lane >> 4) * 512u + (unsigned)(lane & 15) * 16u;
-    if (rows_valid > 0) {
+    // lane offset inside a group of eight rows (row stride 512 B for the R / D wide tensors, ldz * 4 for z)
+    const unsigned voff128 = (unsigned)(lane >> 3) * 512u + (unsigned)(lane & 7) * 16u;
+    auto store_sig = [&](auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
       if constexpr (SAVE) {
-        store_half<PITCH>(u[4], u[5], stage, a.ag_out + row0 * D, voff128, 512u, rows_valid, lane);
-        store_half<PITCH>(u[6], u[7], stage, a.ag_out + row0 * D + 64, voff128, 512u, rows_valid, lane);
+#pragma unroll
+        for (int j = 0; j < C::D32; ++j)
+          store_tile<PITCH, FULL, NOST>(u[C::D32 + j], stage, a.ag_out + row0 * D + 32 * j, voff128, 512u, rows_valid, lane);
       }
+    };
+    auto store_z = [&](auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
       if (a.z_out) {
         const unsigned ldzb = (unsigned)a.ldz * 4u;
-        const unsigned voffz = (unsigned)(lane >> 4) * ldzb + (unsigned)(lane & 15) * 16u;
-        store_half<PITCH>(u[0], u[1], stage, a.z_out + row0 * a.ldz, voffz, ldzb, rows_valid, lane);
-        store_half<PITCH>(u[2], u[3], stage, a.z_out + row0 * a.ldz + 64, voffz, ldzb, rows_valid, lane);
+        const unsigned voffz = (unsigned)(lane >> 3) * ldzb + (unsigned)(lane & 7) * 16u;
+#pragma unroll
+        for (int j = 0; j < C::D32; ++j)
+          store_tile<PITCH, FULL, NOST>(u[j], stage, a.z_out + row0 * a.ldz + 32 * j, voffz, ldzb, rows_valid, lane);
       }
-    }
-
+    };
+    if (rows_valid == 32) { store_sig(std::true_type{}); store_z(std::true_type{}); }
+    else if (rows_valid > 0) { store_sig(std::false_type{}); store_z(std::false_type{}); }
     // The residual (x itself, or a separate tensor: dropout feeds the conv a dropped copy, queued generation ring rows) is
-    // re-read here in D layout, ahead of the 1x1 whose products hide its latency: keeping the newest tap's 64 registers
-    // alive through the conv does not fit beside the 128 accumulators (the compiler spills all of them).
+    // re-read here, ahead of the 1x1 whose products hide part of its latency, in the STORE layout of x_out (lane = 16 bytes of a
+    // 128-byte row segment, 8 rows per instruction: whole cache lines) and added on the way out.  Keeping the newest tap's
+    // 64 registers alive through the conv does not fit beside the 128 accumulators (the compiler spills all of them), and
+    // a re-read in D layout touches every line from four instructions (measured: 17 of 93 us per launch).
     f32x4 xr[RESMODE == 1 ? C::R32 : 1][4];
+    constexpr int NRES = RESMODE == 1 ? C::R32 * 4 : 0;  // ordinary loads the counted waits below have to step over
     if constexpr (RESMODE == 1) {
-      const char* rbase = reinterpret_cast<const char*>(a.res ? a.res : a.x) + row0 * (R * 4);
-      const unsigned roff = (unsigned)(tin ? tl : 0) * (R * 4u) + 16u * h;
+      const char* rbase0 = reinterpret_cast<const char*>(a.res ? a.res : a.x) + row0 * (R * 4);
+      asm volatile("" : "+s"(rbase0));                   // one scalar base (see store_tile)
+      const __attribute__((address_space(1))) char* rbase = (const __attribute__((address_space(1))) char*)rbase0;
 #pragma unroll
       for (int j = 0; j < C::R32; ++j)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-          xr[j][rq] = *(const __attribute__((address_space(1))) f32x4*)(rbase + (128 * j + 32 * rq) + roff);
+        for (int i = 0; i < 4; ++i) {
+          // rows past the end of the utterance read row 0 of the tile (never stored)
+          const unsigned rr = (unsigned)(i * 8 + (lane >> 3));
+          const unsigned roff = ((int)rr < rows_valid ? rr : 0u) * (R * 4u) + (unsigned)(lane & 7) * 16u;
+          xr[j][i] = *(const __attribute__((address_space(1))) f32x4*)(rbase + 128 * j + roff);
+        }
     }
     // =================== 1x1 residual conv: NC2 chunks of two k-steps; B operand = the z tiles as they stand ===================
     f32x16 o[C::R32];
@@ -281,11 +312,13 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     wn_static_for<C::NC2>([&](auto cc_) {
       constexpr int cc = decltype(cc_)::value;
       constexpr int c = NC1 + cc;
-      // (the last pass's two look-ahead chunks are re-reads of chunks 0, 1 nobody uses: the counted waits stay the same)
-      wdma((c + 2) % NCH, (ring0 + c + 2) & (C::NBUF - 1));
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+      // loads younger than w(c): w(c+1), and the residual loads when they were issued after w(c) (c = NC1: w(c) from step
+      // NC1 - 2, w(c+1) from step NC1 - 1, then the residual loads; c = NC1 + 1: the residual loads, then w(c+1))
+      constexpr int nyl = PT + (cc < 2 ? NRES : 0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nyl) : "memory");
       asm volatile("s_barrier" ::: "memory");
-      const h8* wl = reinterpret_cast<const h8*>(smem + ((ring0 + c) & (C::NBUF - 1)) * C::CHUNK) + lane;
+      const int slot2 = next_slot(next_slot(slot));
+      const h8* wl = reinterpret_cast<const h8*>(smem + slot * C::CHUNK) + lane;
       h8 fr[2][2];
       fr[0][0] = wl[0];
       fr[0][1] = wl[64];
@@ -305,40 +338,48 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
             fr[(blk + 1) & 1][0] = wl[((blk + 1) * 2 + 0) * 64];
             fr[(blk + 1) & 1][1] = wl[((blk + 1) * 2 + 1) * 64];
           }
-          o[j] = mfma16(fr[blk & 1][1], bh, o[j]);
-          o[j] = mfma16(fr[blk & 1][0], bl, o[j]);
-          o[j] = mfma16(fr[blk & 1][0], bh, o[j]);
+          if constexpr (!(DIAG & 4)) {
+            o[j] = mfma16(fr[blk & 1][1], bh, o[j]);
+            o[j] = mfma16(fr[blk & 1][0], bl, o[j]);
+            o[j] = mfma16(fr[blk & 1][0], bh, o[j]);
+          } else {
+            o[j][0] += (float)fr[blk & 1][1][0] * (float)bh[0] + (float)fr[blk & 1][0][1] * (float)bl[1];
+          }
+          // (past the tile's end: the next tile's first chunks; on the last pass harmless re-reads nobody uses)
+          if constexpr (blk < PT) wpiece((c + 2) % NCH, slot2, blk);
           __builtin_amdgcn_sched_barrier(0);
         });
       });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot = next_slot(slot);
     });
+    slot0 = slot;                                      // NCH % NBUF != 0: the next tile starts where this one ended
 
     // =================== residual, range guard, x_out ===================
-    if (rows_valid > 0) {
+    auto store_out = [&](auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
       if (a.o_out) {
-        store_half<PITCH>(o[0], o[1], stage, a.o_out + row0 * R, voff128, 512u, rows_valid, lane);
-        store_half<PITCH>(o[2], o[3], stage, a.o_out + row0 * R + 64, voff128, 512u, rows_valid, lane);
-      }
-      if constexpr (RESMODE == 1) {
 #pragma unroll
         for (int j = 0; j < C::R32; ++j)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            o[j][4 * rq + 0] += xr[j][rq].x; o[j][4 * rq + 1] += xr[j][rq].y;
-            o[j][4 * rq + 2] += xr[j][rq].z; o[j][4 * rq + 3] += xr[j][rq].w;
-          }
+          store_tile<PITCH, FULL, NOST>(o[j], stage, a.o_out + row0 * R + 32 * j, voff128, 512u, rows_valid, lane);
       }
+      // range guard on max(|o|, |residual|) -- x_out = o + residual is formed on the way out, |x_out| <= 2 max(...): the
+      // limit (3e4) keeps a factor 2 below the fp16 range
       if (tin) {
 #pragma unroll
         for (int j = 0; j < C::R32; ++j)
 #pragma unroll
-          for (int rq = 0; rq < 4; ++rq)
+          for (int rq = 0; rq < 4; ++rq) {
             wmax = wn_absmax_acc(wmax, o[j][4 * rq + 0], o[j][4 * rq + 1], o[j][4 * rq + 2], o[j][4 * rq + 3]);
+            if constexpr (RESMODE == 1) wmax = wn_absmax_acc(wmax, xr[j][rq].x, xr[j][rq].y, xr[j][rq].z, xr[j][rq].w);
+          }
       }
-      store_half<PITCH>(o[0], o[1], stage, a.x_out + row0 * R, voff128, 512u, rows_valid, lane);
-      store_half<PITCH>(o[2], o[3], stage, a.x_out + row0 * R + 64, voff128, 512u, rows_valid, lane);
-    }
+#pragma unroll
+      for (int j = 0; j < C::R32; ++j)
+        store_tile<PITCH, FULL, NOST, RESMODE == 1>(o[j], stage, a.x_out + row0 * R + 32 * j, voff128, 512u, rows_valid, lane,
+                                                    xr[RESMODE == 1 ? j : 0]);
+    };
+    if (rows_valid == 32) store_out(std::true_type{});
+    else if (rows_valid > 0) store_out(std::false_type{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead chunks land before the LDS is given back
   if (a.absmax_out) {
@@ -360,12 +401,24 @@ int wn_launch_layer_fwd_s128(const WnLayerFwdArgs& a, hipStream_t s) {
   if (a.z_out && (a.ldz % 4 != 0)) { wn_set_error("layer_fwd_s128: z row stride must be a multiple of 4"); return WN_E_UNSUPPORTED; }
   const int64_t tiles = (int64_t)a.B * ((a.T + 31) / 32);
   if (tiles <= 0) return WN_OK;
-  int64_t gx = (tiles + 7) / 8;
-  if (gx > 256) gx = 256;                    // one persistent workgroup per CU
+  int64_t gx = (tiles + 3) / 4;
+  if (gx > 512) gx = 512;                    // two persistent workgroups of four waves per CU
   const int resmode = a.residual ? 1 : 0;
   const bool save = a.ag_out != nullptr;
 #define WN_S128_LAUNCH(RM_, SV_) \
-  hipLaunchKernelGGL((wn_layer_fwd_s128_kernel<2, RM_, SV_>), dim3((unsigned)gx), dim3(512), 0, s, a)
+  hipLaunchKernelGGL((wn_layer_fwd_s128_kernel<2, RM_, SV_>), dim3((unsigned)gx), dim3(256), 0, s, a)
+#ifdef WN_S128_DIAG
+  if (resmode == 1 && save && wn_debug_get(29) != 0) {   // timing ablations of the training form (tools/time_s128.py)
+#define WN_S128_D(D_) case D_: hipLaunchKernelGGL((wn_layer_fwd_s128_kernel<2, 1, true, D_>), dim3((unsigned)gx), dim3(256), 0, s, a); break;
+    switch (wn_debug_get(29)) {
+      WN_S128_D(1) WN_S128_D(2) WN_S128_D(4) WN_S128_D(8) WN_S128_D(16) WN_S128_D(32) WN_S128_D(19) WN_S128_D(12) WN_S128_D(51) WN_S128_D(63)
+      default: wn_set_error("layer_fwd_s128: no such ablation"); return WN_E_INVALID;
+    }
+#undef WN_S128_D
+    WN_HIP_CHECK(hipGetLastError());
+    return WN_OK;
+  }
+#endif
   if (resmode == 0) { if (save) WN_S128_LAUNCH(0, true); else WN_S128_LAUNCH(0, false); }
   else { if (save) WN_S128_LAUNCH(1, true); else WN_S128_LAUNCH(1, false); }
 #undef WN_S128_LAUNCH

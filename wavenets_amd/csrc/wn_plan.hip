@@ -124,6 +124,8 @@ struct wn_plan {
   // wn_stack_prof_enable: event pairs around the whole residual-block stack forward (first block launch -> end of
   // the folded skip contraction): SURVEY.md 8(d)'s t_stack_fwd
   std::vector<hipEvent_t> stack_ev;
+  std::vector<hipEvent_t> foldprep_ev;   // pairs around the per-pass weight-space preparation of the folded skip path
+  int foldprep_used = 0;
   int stack_used = 0;
 };
 
@@ -1095,6 +1097,7 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_cov_fold) (void)hipFree(p->d_cov_fold);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->stack_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->foldprep_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->phase_ev) if (e) (void)hipEventDestroy(e);
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
@@ -1137,13 +1140,34 @@ extern "C" int wn_prof_enable(wn_plan* p, int32_t max_launches) {
 extern "C" int wn_stack_prof_enable(wn_plan* p, int32_t max_passes) {
   if (!p) return WN_E_INVALID;
   for (hipEvent_t e : p->stack_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->foldprep_ev) (void)hipEventDestroy(e);
   p->stack_ev.clear();
+  p->foldprep_ev.clear();
   p->stack_used = 0;
+  p->foldprep_used = 0;
   for (int i = 0; i < 2 * max_passes; ++i) {
     hipEvent_t e;
     WN_HIP_CHECK(hipEventCreate(&e));
     p->stack_ev.push_back(e);
+    WN_HIP_CHECK(hipEventCreate(&e));
+    p->foldprep_ev.push_back(e);
   }
+  return WN_OK;
+}
+// the same passes' weight-space preparation of the folded skip path (bias sum, V = W_s W_f0, its fp16 images), which
+// runs before the first block launch: average per pass, 0 when the plan does not fold.  Call BEFORE wn_stack_prof_read.
+extern "C" int wn_stack_prof_read_foldprep(wn_plan* p, int32_t* passes, float* avg_ms) {
+  if (!p || !passes || !avg_ms) return WN_E_INVALID;
+  double tot = 0.0;
+  int n = 0;
+  for (int i = 0; i + 1 < p->foldprep_used; i += 2) {
+    float ms = 0.f;
+    WN_HIP_CHECK(hipEventElapsedTime(&ms, p->foldprep_ev[i], p->foldprep_ev[i + 1]));
+    tot += ms; ++n;
+  }
+  *passes = n;
+  *avg_ms = n ? (float)(tot / n) : 0.f;
+  p->foldprep_used = 0;
   return WN_OK;
 }
 extern "C" int wn_stack_prof_read(wn_plan* p, int32_t* passes, float* avg_ms) {
@@ -1328,6 +1352,8 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = wn_launch_prep_table(p->d_prep, (int)p->prep.size(), params, fragbase, s);
     if (rc) return rc;
   }
+  const bool fp_prof = prep && fold_ok(p) && p->foldprep_used + 2 <= (int)p->foldprep_ev.size();
+  if (fp_prof) (void)hipEventRecord(p->foldprep_ev[p->foldprep_used], s);
   // bias of the folded skip sum = sum over blocks of conv_skip (or conv1) biases
   if (prep && p->c.use_skip) {
     const ConvInfo& c0 = p->blocks[0].has_skip ? p->blocks[0].conv_skip : p->blocks[0].conv1;
@@ -1351,6 +1377,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = wn_launch_prep_table(p->d_prep2, (int)p->prep2.size(), ws, fragbase, s);      // sources relative to the workspace
     if (rc) return rc;
   }
+  if (fp_prof) { (void)hipEventRecord(p->foldprep_ev[p->foldprep_used + 1], s); p->foldprep_used += 2; }
   // conditioning: mapping Dense stack + per-block time-invariant bias  (src/model.py:221-225,
   // src/layers.py:203-204: conv_cond(repeat(m)) == per-utterance bias)
   const float* m = cond;
