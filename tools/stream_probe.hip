@@ -15,14 +15,14 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // WPC / XPC: 1 KiB DMA instructions per wave and chunk for weights / activations; SPT: 1 KiB store instructions per wave
 // and tile (a tile = NCH chunks); MF: MFMAs per wave and chunk; LR: 1 = read the weight fragments from LDS
-template <int WPC, int XPC, int SPT, int MF, int LR, int NCH>
-__global__ __launch_bounds__(512, 2) void probe(const f32x4* __restrict__ w, int wchunks, const f32x4* __restrict__ x,
+template <int WPC, int XPC, int SPT, int MF, int LR, int NCH, int WAVES = 8, int XD = 4>
+__global__ __launch_bounds__(64 * WAVES, 2) void probe(const f32x4* __restrict__ w, int wchunks, const f32x4* __restrict__ x,
                                                 size_t xmask, f32x4* __restrict__ y, size_t ymask, int ntiles, float* out,
                                                 unsigned long long* cyc) {
-  constexpr int WCH = (WPC > 0 ? WPC : 1) * 8 * 1024, XB = (XPC > 0 ? XPC : 1) * 1024;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WCH + 8 * 4 * XB];
+  constexpr int WCH = (WPC > 0 ? WPC : 1) * WAVES * 1024, XB = (XPC > 0 ? XPC : 1) * 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WCH + WAVES * XD * XB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned char* xbuf = smem + 4 * WCH + wave * 4 * XB;
+  unsigned char* xbuf = smem + 4 * WCH + wave * XD * XB;
   f32x16 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -34,31 +34,33 @@ __global__ __launch_bounds__(512, 2) void probe(const f32x4* __restrict__ w, int
   auto wdma = [&](int c) {
 #pragma unroll
     for (int i = 0; i < WPC; ++i) {
-      const f32x4* src = w + ((size_t)(c % wchunks) * WPC * 8 + i * 8 + wave) * 64 + lane;
-      DMA(src, smem + (c & 3) * WCH + (i * 8 + wave) * 1024);
+      const f32x4* src = w + ((size_t)(c % wchunks) * WPC * WAVES + i * WAVES + wave) * 64 + lane;
+      DMA(src, smem + (c & 3) * WCH + (i * WAVES + wave) * 1024);
     }
   };
   auto xdma = [&](int c) {
 #pragma unroll
     for (int i = 0; i < XPC; ++i) {
-      const size_t o = (wgbase + ((xc++) * 8 + wave) * 64) & xmask;
-      DMA(x + o + lane, xbuf + (c & 3) * XB + i * 1024);
+      const size_t o = (wgbase + ((xc++) * WAVES + wave) * 64) & xmask;
+      DMA(x + o + lane, xbuf + (c % XD) * XB + i * 1024);
     }
   };
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   int c = 0;
   for (int tile = 0; tile < ntiles; ++tile) {
     __syncthreads();
-    wdma(c); xdma(c); wdma(c + 1); xdma(c + 1); xdma(c + 2);
+    wdma(c); xdma(c); wdma(c + 1);
+#pragma unroll
+    for (int q = 1; q < XD - 1; ++q) xdma(c + q);
     for (int k = 0; k < NCH; ++k, ++c) {
       wdma(c + 2);
-      xdma(c + 3);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPC + 3 * XPC) : "memory");
+      xdma(c + XD - 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPC + (XD - 1) * XPC) : "memory");
       asm volatile("s_barrier" ::: "memory");
       const h8* wl = reinterpret_cast<const h8*>(smem + (c & 3) * WCH) + lane;
       h8 bh = {1, 1, 1, 1, 1, 1, 1, 1};
       if (XPC > 0) {
-        const f32x4 xv = *(reinterpret_cast<const f32x4*>(xbuf + (c & 3) * XB) + lane);
+        const f32x4 xv = *(reinterpret_cast<const f32x4*>(xbuf + (c % XD) * XB) + lane);
         bh[0] = (_Float16)xv.x; bh[1] = (_Float16)xv.y;
       }
 #pragma unroll
@@ -77,11 +79,11 @@ __global__ __launch_bounds__(512, 2) void probe(const f32x4* __restrict__ w, int
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    c += 3;
+    c += XD - 1;
     // epilogue stores: SPT KiB per wave
 #pragma unroll 8
     for (int i = 0; i < SPT; ++i) {
-      const size_t o = (wgbase + ((yc++) * 8 + wave) * 64) & ymask;
+      const size_t o = (wgbase + ((yc++) * WAVES + wave) * 64) & ymask;
       f32x4 v = {acc[i & 7][0], acc[i & 7][1], acc[i & 7][2], sink.x};
       y[o + lane] = v;
     }
@@ -94,31 +96,31 @@ __global__ __launch_bounds__(512, 2) void probe(const f32x4* __restrict__ w, int
   if (s == 12345.678f) out[0] = s;
 }
 
-template <int WPC, int XPC, int SPT, int MF, int LR, int NCH>
+template <int WPC, int XPC, int SPT, int MF, int LR, int NCH, int WAVES = 8, int XD = 4>
 static void run(const char* name, const f32x4* w, const f32x4* x, size_t xmask, f32x4* y, size_t ymask, float* out,
                 unsigned long long* cyc, int wgs) {
   const int ntiles = 40, wchunks = 20;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<WPC, XPC, SPT, MF, LR, NCH>), dim3(wgs), dim3(512), 0, 0, w, wchunks, x, xmask, y, ymask, ntiles, out, cyc);
+  hipLaunchKernelGGL((probe<WPC, XPC, SPT, MF, LR, NCH, WAVES, XD>), dim3(wgs), dim3(64 * WAVES), 0, 0, w, wchunks, x, xmask, y, ymask, ntiles, out, cyc);
   hipEventRecord(e0);
   const int reps = 3;
   for (int i = 0; i < reps; ++i)
-    hipLaunchKernelGGL((probe<WPC, XPC, SPT, MF, LR, NCH>), dim3(wgs), dim3(512), 0, 0, w, wchunks, x, xmask, y, ymask, ntiles, out, cyc);
+    hipLaunchKernelGGL((probe<WPC, XPC, SPT, MF, LR, NCH, WAVES, XD>), dim3(wgs), dim3(64 * WAVES), 0, 0, w, wchunks, x, xmask, y, ymask, ntiles, out, cyc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
-  unsigned long long hc[1024];
+  unsigned long long hc[2048];
   hipMemcpy(hc, cyc, sizeof(unsigned long long) * wgs, hipMemcpyDeviceToHost);
   double cs = 0;
   for (int i = 0; i < wgs; ++i) cs += (double)hc[i];
   cs /= wgs;
   const double us_tile = ms * 1e3 / reps / ntiles;
-  const double kib_tile = NCH * (WPC * 8.0 + XPC * 8.0) + SPT * 8.0;     // per workgroup
+  const double kib_tile = NCH * (WPC * 1.0 * WAVES + XPC * 1.0 * WAVES) + SPT * 1.0 * WAVES;     // per workgroup
   printf("%-44s wgs %4d: %7.2f us/tile  %8.0f clk/tile  %6.1f B/clk/CU  (w %4.0f x %4.0f st %4.0f KiB/tile)  chip %6.2f TB/s hbm-side %6.2f TB/s\n",
-         name, wgs, us_tile, cs / ntiles, kib_tile * 1024 / (cs / ntiles), NCH * WPC * 8.0, NCH * XPC * 8.0, SPT * 8.0,
-         kib_tile * 1024 * wgs / us_tile / 1e6, (NCH * XPC * 8.0 + SPT * 8.0) * 1024 * wgs / us_tile / 1e6);
+         name, wgs, us_tile, cs / ntiles, kib_tile * 1024 / (cs / ntiles), NCH * WPC * 1.0 * WAVES, NCH * XPC * 1.0 * WAVES, SPT * 1.0 * WAVES,
+         kib_tile * 1024 * wgs / us_tile / 1e6, (NCH * XPC * 1.0 * WAVES + SPT * 1.0 * WAVES) * 1024 * wgs / us_tile / 1e6);
 }
 
 int main() {
@@ -129,20 +131,24 @@ int main() {
   hipMalloc(&w, 1 << 20); hipMalloc(&x, xbytes); hipMalloc(&y, ybytes); hipMalloc(&out, 4); hipMalloc(&cyc, 8 * 1024);
   hipMemset(w, 0, 1 << 20); hipMemset(x, 0, xbytes);
   const size_t xmask = xbytes / 16 - 1 - 63, ymask = ybytes / 16 - 1 - 63;   // keeps 64-piece alignment
-  for (int wgs : {256}) {
-    run<2, 0, 0, 0, 0, 20>("W only (L2 stream, 16 KiB/chunk)", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<2, 0, 0, 0, 1, 20>("W + LDS fragment reads", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<0, 2, 0, 0, 0, 20>("X only (HBM stream, 16 KiB/chunk)", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<0, 3, 0, 0, 0, 20>("X only, 24 KiB/chunk", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<2, 2, 0, 0, 0, 20>("W + X", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<2, 2, 0, 24, 1, 20>("W + X + LDS + 24 MFMA", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<0, 0, 0, 24, 0, 20>("24 MFMA only", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<0, 2, 48, 0, 0, 20>("X + stores (48 KiB/wave/tile)", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<2, 2, 48, 0, 0, 20>("W + X + stores", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<2, 2, 48, 24, 1, 20>("W + X + stores + LDS + 24 MFMA (skeleton)", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<2, 2, 32, 24, 1, 20>("skeleton, no sigmoid store", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<2, 3, 48, 24, 1, 20>("skeleton + residual re-read", w, x, xmask, y, ymask, out, cyc, wgs);
-    run<1, 2, 48, 24, 1, 20>("skeleton, half the weights (512 rows/pass)", w, x, xmask, y, ymask, out, cyc, wgs);
-  }
+  const int wgs = 256;
+  printf("--- 8 waves, 1 workgroup per CU; x ring depth 4 (3 k-steps in flight) unless stated ---\n");
+  run<2, 0, 0, 0, 0, 20>("W only (L2 stream, 16 KiB/chunk)", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<0, 2, 0, 0, 0, 20>("X only (HBM stream, 16 KiB/chunk)", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<2, 2, 0, 0, 0, 20>("W + X", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<0, 0, 0, 24, 0, 20>("24 MFMA only", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<2, 2, 0, 24, 1, 20>("W + X + LDS + 24 MFMA", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<2, 2, 0, 24, 1, 20, 8, 3>("W + X + LDS + 24 MFMA, x ring 3", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<2, 2, 0, 24, 1, 20, 8, 6>("W + X + LDS + 24 MFMA, x ring 6", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<0, 2, 0, 24, 0, 20, 8, 4>("X + 24 MFMA (no weights)", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<0, 2, 0, 24, 0, 20, 8, 8>("X + 24 MFMA (no weights), x ring 8", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<0, 2, 48, 0, 0, 20>("X + stores (48 KiB/wave/tile)", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<2, 2, 48, 24, 1, 20>("W + X + stores + LDS + 24 MFMA (skeleton)", w, x, xmask, y, ymask, out, cyc, wgs);
+  run<2, 2, 48, 24, 1, 20, 8, 6>("skeleton, x ring 6", w, x, xmask, y, ymask, out, cyc, wgs);
+  printf("--- 4 waves, 2 workgroups per CU (512 workgroups) ---\n");
+  run<4, 2, 0, 24, 1, 20, 4, 3>("W + X + LDS + 24 MFMA, x ring 3", w, x, xmask, y, ymask, out, cyc, 512);
+  run<4, 2, 0, 24, 1, 20, 4, 6>("W + X + LDS + 24 MFMA, x ring 6", w, x, xmask, y, ymask, out, cyc, 512);
+  run<4, 2, 48, 24, 1, 20, 4, 3>("skeleton, x ring 3", w, x, xmask, y, ymask, out, cyc, 512);
+  run<4, 2, 48, 24, 1, 20, 4, 6>("skeleton, x ring 6", w, x, xmask, y, ymask, out, cyc, 512);
   return 0;
 }

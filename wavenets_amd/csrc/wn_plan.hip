@@ -100,6 +100,7 @@ struct wn_plan {
   WnWgPair* d_pairs = nullptr;
   int pair_first[3] = {0, 0, 0}, pair_count[3] = {0, 0, 0};
   bool jobs_pairk = false;
+  bool jobs_pair_dual = false;
   // the head layers' weight gradients as staged pair jobs (kinds 1..4) on the head's own time split
   int hpair_first[6] = {0, 0, 0, 0, 0, 0}, hpair_count[6] = {0, 0, 0, 0, 0, 0};
   bool jobs_headpairs = false;
@@ -1588,13 +1589,16 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool pairk = !layerk && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
                      wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
                      wn_debug_get(13) != 1;
+  // knob 16 = 2: both taps of a block's gated conv as ONE job (du read once).  Measured slower at configs[3] (22.1 vs
+  // 16.4 ms per step): 128 accumulator registers per wave beside the staging registers spill (80 VGPRs)
+  const bool pair_dual = pairk && wn_debug_get(16) == 2;
   const bool fold = fold_ok(p);
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
   // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
   const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
+      p->jobs_pairk == pairk && p->jobs_pair_dual == pair_dual && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
   std::vector<WnWgLayer> wgl;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
@@ -1629,6 +1633,16 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       wgl.push_back(w);
     } else if (pairk) {
       const int64_t xoff = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
+      if (pair_dual) {
+        // both taps in one job: x[t - d] | x[t] against ONE read of du (kind 6)
+        WnWgPair w;
+        memset(&w, 0, sizeof(w));
+        w.x_off = xoff; w.g_off = L.GU[b]; w.shift = c.dil;
+        w.w_off = p->tensors[c.kernel_t].off;
+        w.b_off = p->tensors[c.bias_t].off;
+        w.gmax_off = am_GU(b);
+        pairs[1].push_back(w);
+      } else
       for (int t = 0; t < p->KS; ++t) {
         WnWgPair w;
         memset(&w, 0, sizeof(w));
@@ -1714,7 +1728,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_dual = pair_dual; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
   p->jobs_fold = fold;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
@@ -2063,8 +2077,8 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
     for (int kd = 1; kd <= 2; ++kd)
       if (p->jobs_pairk && p->pair_count[kd] > 0) {
-        rc = wn_launch_wgrad_pairs(kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws, ws + L.bslab, p->nparams, B, T,
-                                   L.bsplits, s);
+        rc = wn_launch_wgrad_pairs(kd == 1 && p->jobs_pair_dual ? 6 : kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws,
+                                   ws + L.bslab, p->nparams, B, T, L.bsplits, s);
         if (rc) return rc;
       }
     if (p->jobs_layerk) {

@@ -19,13 +19,16 @@
 
 typedef _Float16 wp_h8 __attribute__((ext_vector_type(8)));
 
-template <int LDX, int LDG, int KT, int NT, int LDW = 32 * NT>
-__global__ __launch_bounds__(64 * (KT / 2) * (NT / 2)) void wn_wgrad_pair_kernel(const WnWgPair* jobs, float* ws, float* slab,
+// DUAL: the X operand is BOTH taps of a kernel-size-2 convolution, channels [0, KC/2) = x[t - shift], [KC/2, KC) = x[t]
+// (same tensor), against ONE read of G: dW of tap 0 and tap 1 are adjacent in the flat layout (tap-major (2, R, N)), so
+// the 32 KT output rows are simply rows of the two stacked matrices.  TK_ = row tiles per wave.
+template <int LDX, int LDG, int KT, int NT, int LDW = 32 * NT, int TK_ = 2, bool DUAL = false>
+__global__ __launch_bounds__(64 * (KT / TK_) * (NT / 2)) void wn_wgrad_pair_kernel(const WnWgPair* jobs, float* ws, float* slab,
                                                                                 int64_t P, int B, int T, int spb) {
   constexpr int KC = 32 * KT, NC = 32 * NT, NCH = KC + NC;
   constexpr int PLANE = NCH * 32;                        // bytes of one fp16 plane of a stage
   constexpr int STAGE = 2 * PLANE;
-  constexpr int TK = 2, TN = 2, WKD = KT / TK, NW = (KT / TK) * (NT / TN), NTHR = 64 * NW;
+  constexpr int TK = TK_, TN = 2, WKD = KT / TK, NW = (KT / TK) * (NT / TN), NTHR = 64 * NW;
   static_assert(KT % TK == 0 && NT % TN == 0 && 2 * KC <= NTHR && 2 * NC <= NTHR, "tile shape");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * NC * 4];
   float* bpart = reinterpret_cast<float*>(smem + 2 * STAGE);
@@ -55,12 +58,13 @@ __global__ __launch_bounds__(64 * (KT / 2) * (NT / 2)) void wn_wgrad_pair_kernel
   const bool xunit = tid < 2 * KC, gunit = tid < 2 * NC;
   const int cx = xunit ? tid % KC : 0, hx = xunit ? tid / KC : 0;
   const int cg = gunit ? tid % NC : 0, hg = gunit ? tid / NC : 0;
-  const float* xptr = ws + J.x_off + (int64_t)ub * T * LDX + cx;
+  const int xshift = DUAL ? (cx < KC / 2 ? shift : 0) : shift;      // this unit's tap
+  const float* xptr = ws + J.x_off + (int64_t)ub * T * LDX + (DUAL ? cx % (KC / 2) : cx);
   const float* gptr = ws + J.g_off + (int64_t)ub * T * LDG + cg;
   float bsum = 0.f;
 
   auto load_chunk = [&](int t0, float (&xv)[8], float (&gv)[8]) {
-    const int tx = t0 + 8 * hx - shift;
+    const int tx = t0 + 8 * hx - xshift;
     const float* px = xptr + (int64_t)tx * LDX;
     const float* pg = gptr + (int64_t)(t0 + 8 * hg) * LDG;
     if (t0 + 16 <= r1 && t0 - shift >= 0) {              // workgroup-uniform: an interior chunk needs no masks
@@ -117,21 +121,44 @@ __global__ __launch_bounds__(64 * (KT / 2) * (NT / 2)) void wn_wgrad_pair_kernel
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   auto compute = [&](int stage) {
     const unsigned char* st = smem + stage * STAGE + tl * 32 + h * 16;
-    wp_h8 ah[TK], al[TK];
-#pragma unroll
-    for (int i = 0; i < TK; ++i) {
-      ah[i] = *reinterpret_cast<const wp_h8*>(st + (32 * (wk * TK + i)) * 32);
-      al[i] = *reinterpret_cast<const wp_h8*>(st + PLANE + (32 * (wk * TK + i)) * 32);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const wp_h8 bh = *reinterpret_cast<const wp_h8*>(st + (KC + 32 * (wn * TN + j)) * 32);
-      const wp_h8 bl = *reinterpret_cast<const wp_h8*>(st + PLANE + (KC + 32 * (wn * TN + j)) * 32);
+    if constexpr (TK <= 2) {
+      wp_h8 ah[TK], al[TK];
 #pragma unroll
       for (int i = 0; i < TK; ++i) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+        ah[i] = *reinterpret_cast<const wp_h8*>(st + (32 * (wk * TK + i)) * 32);
+        al[i] = *reinterpret_cast<const wp_h8*>(st + PLANE + (32 * (wk * TK + i)) * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const wp_h8 bh = *reinterpret_cast<const wp_h8*>(st + (KC + 32 * (wn * TN + j)) * 32);
+        const wp_h8 bl = *reinterpret_cast<const wp_h8*>(st + PLANE + (KC + 32 * (wn * TN + j)) * 32);
+#pragma unroll
+        for (int i = 0; i < TK; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
+      }
+    } else {
+      // more row tiles per wave: the G fragments stay, the X fragments are fetched per row tile (register pressure:
+      // 16 * TK * TN accumulators; same products in the same order per output element)
+      wp_h8 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const wp_h8*>(st + (KC + 32 * (wn * TN + j)) * 32);
+        bl[j] = *reinterpret_cast<const wp_h8*>(st + PLANE + (KC + 32 * (wn * TN + j)) * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < TK; ++i) {
+        const wp_h8 ah = *reinterpret_cast<const wp_h8*>(st + (32 * (wk * TK + i)) * 32);
+        const wp_h8 al = *reinterpret_cast<const wp_h8*>(st + PLANE + (32 * (wk * TK + i)) * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -195,6 +222,8 @@ int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws
     case 4: hipLaunchKernelGGL((wn_wgrad_pair_kernel<256, 256, 8, 8>), grid, dim3(1024), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
     // a 128-column half of a 256 x 256 product: G rows and dW rows keep their pitch of 256
     case 5: hipLaunchKernelGGL((wn_wgrad_pair_kernel<256, 256, 8, 4, 256>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
+    // both taps of a 128 -> 256 kernel-size-2 convolution from one read of G (4 x 2 tiles per wave, 8 waves)
+    case 6: hipLaunchKernelGGL((wn_wgrad_pair_kernel<128, 256, 8, 8, 256, 4, true>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
     default: wn_set_error("wgrad_pairs: unknown kind %d", kind); return WN_E_UNSUPPORTED;
   }
   WN_HIP_CHECK(hipGetLastError());
