@@ -185,6 +185,11 @@ int wn_generate(wn_plan* p, const float* params, const float* window, const floa
                 int32_t length, int32_t deterministic, int32_t queued, uint64_t seed, float* out,
                 float* workspace, int64_t ws_floats, void* stream);
 int64_t wn_generate_workspace_floats(const wn_plan* p, int32_t B, int32_t queued);
+/* float offset, inside the caller's generation workspace, of the call's range-guard slot: after wn_generate (stream
+ * synchronised) it holds the largest |activation| any split-precision kernel of the call was fed (priming pass, per-step
+ * blocks, the fused chain kernel's residual stream and folded skip sum); at or beyond wn_range_limit() the samples are
+ * not valid and the call is to be repeated with the exact-fp32 kernels (wn_debug_set(1, 1)). */
+int64_t wn_generate_guard_slot(const wn_plan* p, int32_t B, int32_t queued);
 
 /* ---- WaveNetLayer.call, src/layers.py:178-224, standalone block ----
  * weights in Keras layout: dil_kernels = layers_in_block kernels concatenated

@@ -191,3 +191,46 @@ def test_30_block_probabilities_and_samples(name):
     top2 = torch.topk(w, 2, dim=-1).values
     clear = ((top2[..., 0] - top2[..., 1]) > 1e-3).unsqueeze(-1)
     assert (got[clear] - want[clear]).abs().max().item() < ATOL_ACT
+
+
+@pytest.mark.parametrize('name', ['configs1_cat_r64', 'configs3_mol10_r128'])
+@pytest.mark.parametrize('queued', [False, True])
+def test_30_block_generation_matches_oracle(name, queued):
+  """generate (src/model.py:258-307, intended semantics) on the exact BASELINE networks, receptive field 3071, B = 2,
+  8 samples, deterministic draws, for both samplers -- the sliding window and the queued one (README.md:16) -- against
+  the oracle's sliding window in fp64.  Categorical: the emitted left bin edges must agree exactly wherever the
+  oracle's own top-2 probabilities are further apart than the activation tolerance; a step that is not clear ends the
+  comparison (later inputs may legitimately differ).  Mixture: clipped means within 1e-4."""
+  ocfg, params, x, cond, _ = _oracle(name)
+  model = _model(name, params)
+  rf = model.receptive_field
+  assert rf == 3071
+  n = 8
+  w = O.synthetic_waveform(2, rf, seed=77)
+  pd = [p.double() for p in params]
+  # the oracle's sliding window, keeping every step's prediction to judge how clear each decision was
+  xw = w.double().clone()
+  ref, clear = [], []
+  with torch.no_grad():
+    for _ in range(n):
+      pred = O.model_forward(xw, pd, ocfg)[:, -1:, :]
+      smp = O.sample_waveform_deterministic(pred.float(), ocfg).double()
+      if ocfg.sampling_function == 'categorical':
+        top2 = torch.topk(pred, 2, dim=-1).values
+        clear.append(bool(((top2[..., 0] - top2[..., 1]) > 2e-4).all()))
+      else:
+        wts = torch.softmax(pred[..., :ocfg.num_mixtures], -1)
+        top2 = torch.topk(wts, 2, dim=-1).values
+        clear.append(bool(((top2[..., 0] - top2[..., 1]) > 1e-3).all()))
+      ref.append(smp)
+      xw = torch.cat([xw[:, 1:], smp], dim=1)
+  ref = torch.cat(ref, dim=1)
+  out = model.generate(n, sample=w.to(dev()), deterministic=True, use_queues=queued).cpu().double()
+  assert out.shape == (2, n, 1)
+  assert getattr(model, 'generation_guard_trips', 0) == 0
+  upto = n if all(clear) else clear.index(False)
+  assert upto >= 1, 'not even the first decision of the oracle is clear: change the seed'
+  if ocfg.sampling_function == 'categorical':
+    assert torch.equal(out[:, :upto], ref[:, :upto]), (name, queued, upto)
+  else:
+    assert (out[:, :upto] - ref[:, :upto]).abs().max().item() < ATOL_ACT, (name, queued, upto)

@@ -23,8 +23,12 @@ KW = dict(blocks=6, channels=32, skip_channels=64, dilation_bound=8, final_layer
 # fold the skip path into the head and run the two-products-per-launch backward chain
 KW_FOLDED = dict(blocks=5, channels=64, skip_channels=256, dilation_bound=16, final_layers_channels=[128, 64],
                  activation='leaky_relu', bits=8, l2_reg_factor=0.001)
-KWS = {'small': KW, 'folded': KW_FOLDED}
+# the exact BASELINE configs[1] / configs[2] network (30 blocks, dilations 1..512 x3), B_local = 2 x 3500 per rank
+KW_CONFIGS1 = dict(blocks=30, channels=64, skip_channels=256, dilation_bound=1024, final_layers_channels=[128, 256],
+                   activation='leaky_relu', bits=8)
+KWS = {'small': KW, 'folded': KW_FOLDED, 'configs1': KW_CONFIGS1}
 GLOBAL_B, T, STEPS = 4, 300, 3
+LENGTHS = {'configs1': 3500}                      # longer than the receptive field (3071)
 
 
 def _free_port():
@@ -35,9 +39,9 @@ def _free_port():
   return p
 
 
-def _data():
+def _data(net='small'):
   from wavenets_amd.data import synthetic_waveforms
-  return synthetic_waveforms(GLOBAL_B, T + 1, seed=99, device='cpu')
+  return synthetic_waveforms(GLOBAL_B, LENGTHS.get(net, T) + 1, seed=99, device='cpu')
 
 
 def _run_steps(model, x):
@@ -62,7 +66,7 @@ def _worker(rank, world, port, backend, out_dir, dropout, net='small'):
     dist.init_process_group('gloo', rank=rank, world_size=world)
   from wavenets_amd import WaveNet, dp
   model = WaveNet(**KWS[net], dropout=dropout, device=dev, seed=7)
-  x = _data()[dp.shard_rows(GLOBAL_B, world, rank)].to(dev)
+  x = _data(net)[dp.shard_rows(GLOBAL_B, world, rank)].to(dev)
   logs = _run_steps(model, x)
   torch.save({'params': model.flat_params.data.cpu(), 'logs': logs, 'drop_step': model._drop_step},
              os.path.join(out_dir, f'rank{rank}.pt'))
@@ -76,12 +80,13 @@ def _check(tmp_path, backend, dropout=0.0, net='small'):
   r0 = torch.load(tmp_path / 'rank0.pt')
   r1 = torch.load(tmp_path / 'rank1.pt')
   assert torch.equal(r0['params'], r1['params'])                 # replicas stay bit-identical
-  assert r0['logs']['loss'] == r1['logs']['loss'] and r0['logs']['reg_loss'] == r1['logs']['reg_loss']
+  assert r0['logs']['loss'] == r1['logs']['loss'] and r0['logs'].get('reg_loss') == r1['logs'].get('reg_loss')
   assert r0['logs']['mean_squared_error'] == r1['logs']['mean_squared_error']      # metric is reduced too
   return r0
 
 
-@pytest.mark.parametrize('backend,net', [('gloo', 'small'), ('gloo', 'folded'), ('nccl', 'folded')])
+@pytest.mark.parametrize('backend,net', [('gloo', 'small'), ('gloo', 'folded'), ('gloo', 'configs1'), ('nccl', 'folded'),
+                                         ('nccl', 'configs1')])
 def test_two_rank_train_step_equals_single_process(tmp_path, backend, net):
   if backend == 'nccl' and torch.cuda.device_count() < 2:
     pytest.skip('needs 2 GPUs')
@@ -89,11 +94,16 @@ def test_two_rank_train_step_equals_single_process(tmp_path, backend, net):
   r0 = _check(tmp_path, backend, net=net)
   dev = torch.device('cuda', 0)
   single = WaveNet(**KWS[net], device=dev, seed=7)
-  logs = _run_steps(single, _data().to(dev))
+  logs = _run_steps(single, _data(net).to(dev))
   err = (single.flat_params.data.cpu() - r0['params']).abs().max().item()
-  assert err < 1e-5, err
+  # Two shards sum their gradients in a different order than one process over the whole batch (~1e-7 relative).  Keras
+  # Adam turns that into parameter differences of up to a few percent of lr = 5e-4 per step on elements whose gradient
+  # is itself ~1e-7 (update = lr * m / (sqrt(v) + 1e-7)): the 1.25 M-parameter BASELINE network has such elements.
+  tol = 1e-4 if net == 'configs1' else 1e-5
+  assert err < tol, err
   assert abs(logs['loss'] - r0['logs']['loss']) < 1e-5 * abs(logs['loss'])
-  assert abs(logs['reg_loss'] - r0['logs']['reg_loss']) < 1e-6 * max(1.0, abs(logs['reg_loss']))
+  if 'reg_loss' in logs:
+    assert abs(logs['reg_loss'] - r0['logs']['reg_loss']) < 1e-6 * max(1.0, abs(logs['reg_loss']))
 
 
 def test_two_rank_dropout_masks_differ_per_replica(tmp_path):
@@ -105,3 +115,25 @@ def test_two_rank_dropout_masks_differ_per_replica(tmp_path):
   L = _lib.lib()
   keys = {L.wn_dropout_key_for(7, 0, call * 2 + rank + 1) for call in range(STEPS) for rank in range(2)}
   assert len(keys) == 2 * STEPS
+
+
+def test_bench_multi_rank_plumbing_rehearsal():
+  """The SCALE command of the round (`python bench.py --gpus 8 --global-batch 64`, launched by the driver through
+  torch.distributed.run) rehearsed at 2 ranks sharing this box's one GPU over gloo (WN_BENCH_BACKEND=gloo): the
+  self-launch, the rank / device plumbing, the strong-scaling split of the global batch, the barrier + MAX-over-ranks
+  timing and the one JSON line must work before a first real 8-GPU run.  (No throughput is asserted.)"""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, WN_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--global-batch', '4', '--steps', '2', '--warmup', '1',
+         '--length', '3500', '--no-cpu-baseline', '--no-generation', '--no-other-configs']
+  res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+  assert res.returncode == 0, res.stderr[-2000:]
+  line = [ln for ln in res.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln][-1]
+  out = json.loads(line)
+  assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['steps'] == 2
+  assert out['config']['global_batch'] == 4 and out['config']['parallelism'] == 'dp2'
+  assert out['value'] > 0 and abs(out['value'] - 4 * 3500 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-6 * out['value']
+  assert out['roofline']['frac'] > 0 and 'cpu_baseline' not in out

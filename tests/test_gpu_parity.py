@@ -563,6 +563,35 @@ def test_naive_generation_matches_oracle(name):
       pytest.fail(f'generated indices differ first at {first.tolist()}')
 
 
+@pytest.mark.parametrize('queued', [False, True])
+@pytest.mark.parametrize('name', ['cat_r64', 'cat_small_fused'])
+def test_generation_range_guard_repeats_in_exact_fp32(name, queued):
+  """The split-precision kernels cast activations to fp16 hi | lo unscaled (|.| < 65504).  A residual stream of ~1e5
+  (huge input-conv bias) must trip the generate call's guard slot -- priming pass AND the per-step kernels, fused chain
+  included -- and the call must come back as the exact-fp32 result (src/model.py:258-307)."""
+  from wavenets_amd import _lib
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=11, bias_range=0.1, **kw)
+  names = model.variable_names
+  ws = [p.clone() for p in params]
+  ws[names.index('causal/bias')] = torch.full_like(ws[names.index('causal/bias')], 1.0e5)
+  model.set_weights([w.numpy() for w in ws])
+  w0 = O.synthetic_waveform(2, model.receptive_field, seed=3).to(dev())
+  out = model.generate(6, sample=w0, deterministic=True, use_queues=queued)
+  assert model.generation_guard_trips == 1
+  with model.exact_fp32():
+    ref = model.generate(6, sample=w0, deterministic=True, use_queues=queued)
+  assert model.generation_guard_trips == 1            # (exact mode never trips)
+  assert torch.isfinite(out).all() and torch.equal(out, ref)
+  # and a well-scaled net leaves the slot far below the limit
+  ocfg2, params2, model2 = make_pair(seed=11, bias_range=0.1, **kw)
+  model2.generate(6, sample=w0, deterministic=True, use_queues=queued)
+  L = _lib.lib()
+  slot = L.wn_generate_guard_slot(model2._plan, 2, int(queued))
+  v = float(model2._ws['gen'][slot])
+  assert 0.0 < v < 100.0 and getattr(model2, 'generation_guard_trips', 0) == 0
+
+
 def test_generate_errors():
   from wavenets_amd import WaveNet
   m = WaveNet(blocks=2, channels=32, dilation_bound=4, final_layers_channels=[], conditioning='global',

@@ -96,6 +96,7 @@ _SIGS = {
     'wn_generate': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _P,
                               _P, C.c_int64, _P]),
     'wn_generate_workspace_floats': (C.c_int64, [_P, C.c_int32, C.c_int32]),
+    'wn_generate_guard_slot': (C.c_int64, [_P, C.c_int32, C.c_int32]),
     'wn_layer_saved_floats': (C.c_int64, [C.POINTER(WnLayerDesc), C.c_int32, C.c_int32]),
     'wn_layer_workspace_floats': (C.c_int64, [C.POINTER(WnLayerDesc), C.c_int32, C.c_int32]),
     'wn_layer_param_count': (C.c_int64, [C.POINTER(WnLayerDesc)]),

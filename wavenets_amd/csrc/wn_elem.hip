@@ -1129,6 +1129,15 @@ __global__ void wn_guard_flag_kernel(const float* absmax, float limit, int enabl
   const float m = absmax ? *absmax : 0.f;
   out[0] = (enabled && !(m < limit)) ? 1.0f : 0.0f;
 }
+__global__ void wn_guard_accumulate_kernel(const float* src, float* dst) {
+  const unsigned a = __float_as_uint(src[0]) & 0x7fffffffu, b = __float_as_uint(dst[0]) & 0x7fffffffu;
+  dst[0] = __uint_as_float(a > b ? a : b);
+}
+int wn_launch_guard_accumulate(const float* src, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(wn_guard_accumulate_kernel, dim3(1), dim3(1), 0, s, src, dst);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
 int wn_launch_guard_flag(const float* absmax, float limit, int enabled, float* out, hipStream_t s) {
   hipLaunchKernelGGL(wn_guard_flag_kernel, dim3(1), dim3(1), 0, s, absmax, limit, enabled, out);
   WN_HIP_CHECK(hipGetLastError());

@@ -717,6 +717,10 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       }
       put_xop(x, cw);
     }
+    // range guard: running max-abs of the residual stream this wave carries (cast unscaled to fp16 hi | lo by put_xop)
+    float xm = 0.f;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) xm = wn_absmax_acc(xm, x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]);
     GN_BARRIER();
     for (int b0 = 0; b0 < nblocks; b0 += NS)
       wn_static_for<NS>([&](auto sc) {
@@ -746,6 +750,8 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
           gn_mac<KS2>(o, wc[s], reinterpret_cast<const gn_h8*>(zop + (b & 1) * ZOP_BYTES) + lane);
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = a.residual ? o[r] + x[r] : o[r];
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) xm = wn_absmax_acc(xm, x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]);
           if (b + 1 < nblocks) put_xop(x, cw);
           if (cw == 0) GN_TS(1, b, 4);
           GN_BARRIER();                               // (3) x operands visible
@@ -763,6 +769,10 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq)
         *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
+    }
+    if (a.guard) {                                    // one read (and rarely one atomic) per wave and step
+      xm = wn_wave_absmax_bits(live ? xm : 0.f);
+      if (lane == 0) wn_absmax_publish_any(a.guard, xm);
     }
   } else {
     // ================= skip waves: acc_t += W_{s,b}^T z for column tiles t0 = 2 sw and t1 = 2 sw + 1 =================
@@ -875,6 +885,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       gn_vmwait<0>();                                 // the fetch past the last block
     }
     // ---- folded skip sum + summed biases (the epilogue of the rows contraction it replaces) ----
+    float sm = 0.f;
     if (live) {
       auto put = [&](const f32x16& acc, int t) {
         const float* bsp = a.ws + a.skip_bias_off + 32 * t + 4 * h;
@@ -882,13 +893,18 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const f32x4 bv = *reinterpret_cast<const f32x4*>(bsp + 8 * rq);
-          *reinterpret_cast<f32x4*>(dst + 8 * rq) =
-              f32x4{wn_act(acc[4 * rq + 0] + bv.x, a.skip_act), wn_act(acc[4 * rq + 1] + bv.y, a.skip_act),
-                    wn_act(acc[4 * rq + 2] + bv.z, a.skip_act), wn_act(acc[4 * rq + 3] + bv.w, a.skip_act)};
+          const f32x4 o = f32x4{wn_act(acc[4 * rq + 0] + bv.x, a.skip_act), wn_act(acc[4 * rq + 1] + bv.y, a.skip_act),
+                                wn_act(acc[4 * rq + 2] + bv.z, a.skip_act), wn_act(acc[4 * rq + 3] + bv.w, a.skip_act)};
+          *reinterpret_cast<f32x4*>(dst + 8 * rq) = o;
+          sm = wn_absmax_acc(sm, o.x, o.y, o.z, o.w);
         }
       };
       put(acc0, t0);
       if (has1) put(acc1, t1);
+    }
+    if (a.guard) {                                    // the head casts this row to fp16 hi | lo
+      sm = wn_wave_absmax_bits(sm);
+      if (lane == 0) wn_absmax_publish_any(a.guard, sm);
     }
   }
 }

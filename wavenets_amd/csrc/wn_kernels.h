@@ -204,6 +204,8 @@ struct WnGenStepArgs {
   unsigned long long* ts;          // phase stamps (debug switch 24) or null
   int64_t bias_r_off0, bias_r_stride;   // conv1 bias of block b at params + off0 + b * stride (stride 0: not uniform, read the table)
   WnGenBlock blk0[3];              // blocks[0..2] by value (the first fetches do not wait for the table)
+  float* guard;                    // range guard of the generate call: running max-abs of the residual stream and of the
+                                   // folded skip sum (the split-precision casts need |.| < 65504), or null
 };
 // queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)
 struct WnEmit { float* out; int length; int step; float* xin_slot; };
@@ -264,6 +266,8 @@ int wn_launch_inconv_fwd(const float* x, const float* w, const float* bias, int 
                          float* absmax_out, hipStream_t s);
 // out[0] = 1 when the split-precision kernels were fed a forward activation at or beyond `limit` (or a non-finite one)
 int wn_launch_guard_flag(const float* absmax, float limit, int enabled, float* out, hipStream_t s);
+// dst[0] = max(dst[0], src[0]) on the bit patterns (non-negative floats; inf / NaN stay on top)
+int wn_launch_guard_accumulate(const float* src, float* dst, hipStream_t s);
 int wn_launch_gen_tail_cat_det(const float* logits, int rows, int C, int bits, float* out, int length, int step,
                                float* xin_slot, hipStream_t s);
 int wn_launch_batch_reduce(const float* slab, int B, int splits, int N, float* out, hipStream_t s);

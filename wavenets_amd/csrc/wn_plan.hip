@@ -1466,7 +1466,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;      // block-major [N][rows][Dp]
     f.O = nullptr;
     f.x_out = ws + L.H[ho];
-    f.fwd_absmax = rings ? nullptr : fam;
+    f.fwd_absmax = fam;
     const bool prof = p->prof_on && p->prof_used + 2 <= (int)p->prof_ev.size();
     const bool ev0 = prof && (!prof_chain || b == 0), ev1 = prof && (!prof_chain || b == p->N - 1);
     if (ev0) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
@@ -2311,6 +2311,7 @@ namespace {
 struct GenLayout {
   int64_t prime;                       // priming forward workspace (make_layout(B, RF, inference))
   int64_t win0, win1, last, lastp, samp;
+  int64_t guard;                       // range guard of the call: running max-abs of every input of a split-precision kernel
   int64_t xin;                         // [KS][B]
   std::vector<int64_t> ring;           // per block [nslots][B][R]: inputs of the first dilated conv
   std::vector<int> nslots;
@@ -2332,6 +2333,7 @@ GenLayout gen_layout(const wn_plan* p, int B, bool queued) {
   G.last = cv.take((int64_t)B * p->Cout);
   G.lastp = cv.take((int64_t)B * p->Cout);
   G.samp = cv.take(B);
+  G.guard = cv.take(1);
   G.xin = G.Zrow = G.skiprow = G.hrow0 = G.hrow1 = G.dummy = G.u0 = 0;
   if (queued) {
     G.xin = cv.take((int64_t)p->KS * B);
@@ -2382,6 +2384,10 @@ int sample_rows(wn_plan* p, const float* logits_rows, int B, bool deterministic,
 
 }  // namespace
 
+extern "C" int64_t wn_generate_guard_slot(const wn_plan* p, int32_t B, int32_t queued) {
+  if (!p || B < 1) return -1;
+  return gen_layout(p, B, queued != 0).guard;
+}
 extern "C" int64_t wn_generate_workspace_floats(const wn_plan* p, int32_t B, int32_t queued) {
   if (!p || B < 1) return 0;
   return gen_layout(p, B, queued != 0).total;
@@ -2410,11 +2416,19 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   float* samp = workspace + G.samp;
   WN_HIP_CHECK(hipMemcpyAsync(win[0], window, (int64_t)B * RF * sizeof(float), hipMemcpyDeviceToDevice, s));
   int rc;
+  // Range guard (wn_generate_guard_slot): the split-precision kernels cast activations to fp16 hi | lo unscaled, so every
+  // kernel that produces one -- priming pass, per-step blocks, the fused chain kernel -- publishes its running max-abs
+  // here; the caller reads the float after the call and repeats it with the exact-fp32 kernels when it reached
+  // wn_range_limit().  One slot per call: cleared here, only ever raised afterwards.
+  float* const gguard = workspace + G.guard;
+  WN_HIP_CHECK(hipMemsetAsync(gguard, 0, sizeof(float), s));
 
   if (!queued) {
     // ---- naive sliding window: one full forward over the window per sample (src/model.py:296-305) ----
     for (int step = 0; step < length; ++step) {
       rc = forward_core(p, params, win[step & 1], step == 0, cond, B, RF, false, pws, L, s);
+      if (rc) return rc;
+      rc = wn_launch_guard_accumulate(pws + L.fwd_absmax, gguard, s);
       if (rc) return rc;
       hipLaunchKernelGGL(wn_gather_last_kernel, dim3((B * p->Cout + 255) / 256), dim3(256), 0, s, pws + L.logits, B, RF, p->Cout, last);
       rc = sample_rows(p, last, B, deterministic != 0, seed, (uint64_t)step, lastp, samp, s);
@@ -2439,6 +2453,8 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     R.nslots_p.push_back(G.nslots_p[b]);
   }
   rc = forward_core(p, params, win[0], true, cond, B, RF, false, pws, L, s, &R);
+  if (rc) return rc;
+  rc = wn_launch_guard_accumulate(pws + L.fwd_absmax, gguard, s);
   if (rc) return rc;
   hipLaunchKernelGGL(wn_gather_last_kernel, dim3((B * p->Cout + 255) / 256), dim3(256), 0, s, pws + L.logits, B, RF, p->Cout, last);
   rc = sample_rows(p, last, B, deterministic != 0, seed, 0, lastp, samp, s);
@@ -2514,6 +2530,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
         ga.skiprow_off = G.skiprow; ga.skip_ld = skipw; ga.skip_tiles = skipw / 32;
         ga.skip_act = gfold ? p->c.activation : WN_ACT_LINEAR;
       }
+      ga.guard = gguard;
       ga.zrow_off = G.Zrow; ga.hrow_off = p->c.use_skip ? -1 : G.hrow0; ga.tau = tau;
       ga.B = B; ga.nblocks = p->N; ga.residual = p->c.use_residual;
       rc = wn_launch_gen_blocks(ga, p->R, p->KS, (pre_in_head && step > 1) ? 2 : 3, s);
@@ -2563,6 +2580,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       f.O = nullptr;
       f.x_out = (b + 1 < p->N) ? R.h[b + 1] + (int64_t)(tau % R.nslots[b + 1]) * B * p->R
                                : (p->c.use_skip ? workspace + G.dummy : workspace + G.hrow0);
+      f.fwd_absmax = gguard;
       rc = block_forward(k, f, s);
       if (rc) return rc;
     }

@@ -661,9 +661,19 @@ class WaveNet(torch.nn.Module):
     L = _lib.lib()
     ws = self._workspace('gen', L.wn_generate_workspace_floats(self._plan, batch_size, int(bool(use_queues))))
     out = torch.empty(batch_size, int(length), 1, dtype=torch.float32, device=self._device)
-    _lib.check(L.wn_generate(self._plan, _lib.ptr(self.flat_params), _lib.ptr(sample), _lib.ptr(condition),
-                             batch_size, int(length), int(bool(deterministic)), int(bool(use_queues)), 0x0402,
-                             _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    def run():
+      _lib.check(L.wn_generate(self._plan, _lib.ptr(self.flat_params), _lib.ptr(sample), _lib.ptr(condition),
+                               batch_size, int(length), int(bool(deterministic)), int(bool(use_queues)), 0x0402,
+                               _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    run()
+    # range guard (one host read; the caller reads the samples anyway): an activation beyond the fp16 range of the
+    # split-precision kernels -> the whole call again on the exact-fp32 kernels (same seed: same draws)
+    if length > 0 and L.wn_debug_value(1) != 1:
+      slot = L.wn_generate_guard_slot(self._plan, batch_size, int(bool(use_queues)))
+      if not (float(ws[slot]) < L.wn_range_limit()):
+        self.generation_guard_trips = getattr(self, 'generation_guard_trips', 0) + 1
+        with self.exact_fp32():
+          run()
     return out
 
   def compute_receptive_field(self, sampling_frequency):
