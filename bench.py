@@ -127,6 +127,14 @@ OTHER_CONFIGS = {
                         activation='leaky_relu', bits=8, conditioning='global', mapping_layers=[8, 16, 32],
                         mapping_activation='leaky_relu'), 8,
                    'global-conditioned (110-way one-hot speaker id, mapping [8,16,32]), 30 layers, batch 8x16000 per GPU'),
+    # not a BASELINE.json config: the reference's own defaults (train.py:22-50) -- 5 blocks x 5 stacked dilated convs,
+    # 32 channels, gaussian-8 on 16 bits, global conditioning (one-hot(gender, 2), src/utils.py:46-49), dropout 0.1,
+    # dilation_bound 256, batch 64 x 8000 (recording_length 8000)
+    'reference_default': (dict(blocks=5, layers_per_block=5, channels=32, dilation_bound=256, num_mixtures=8,
+                               sampling_function='gaussian', bits=16, conditioning='global', mapping_layers=[8, 16, 32],
+                               mapping_activation='leaky_relu', activation='leaky_relu', final_layers_channels=[128, 256],
+                               dropout=0.1), 64, "the reference's default network (train.py:22-50): 5 blocks x 5 stacked dilated convs, "
+                              '32 ch, gaussian-8, global conditioning, dropout 0.1, batch 64x8000', 8000, 2),
 }
 
 
@@ -137,14 +145,18 @@ def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmu
   from wavenets_amd import WaveNet, Adam, MeanSquaredError
   from wavenets_amd.data import synthetic_waveforms
   res = {}
-  for name, (kw, B, desc) in OTHER_CONFIGS.items():
+  T_default = T
+  for name, entry in OTHER_CONFIGS.items():
+    kw, B, desc = entry[0], entry[1], entry[2]
+    T = entry[3] if len(entry) > 3 else T_default           # samples per utterance
+    n_cond = entry[4] if len(entry) > 4 else 110            # width of the one-hot condition
     m = WaveNet(**kw, device=dev, seed=0)
     m.compile(optimizer=Adam(learning_rate=5e-4, clipnorm=1.0), metrics=[MeanSquaredError()])
     x = synthetic_waveforms(B, T + 1, seed=99, device=dev)
     data = x
     if kw.get('conditioning'):
-      spk = torch.randint(0, 110, (B,), generator=torch.Generator().manual_seed(1))
-      data = (x, torch.nn.functional.one_hot(spk, 110).float().to(dev))
+      spk = torch.randint(0, n_cond, (B,), generator=torch.Generator().manual_seed(1))
+      data = (x, torch.nn.functional.one_hot(spk, n_cond).float().to(dev))
     for _ in range(warmup):
       logs = m.train_step(data)
     torch.cuda.synchronize()
@@ -154,6 +166,7 @@ def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmu
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     nblk = kw['blocks']
+    nconv = nblk * kw.get('layers_per_block', 1)
     _, avg_ms, n_s, stack_ms, prep_ms = stack_profile(m, data, 5, nblk)
     R = kw['channels']
     S_eff = kw.get('skip_channels') or R

@@ -112,7 +112,8 @@ int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
 /* test / diagnosis hook: float offset and length, inside the caller's TRAINING workspace for (B, T), of an
  * intermediate the last wn_train_fwd_bwd left there (deferred weight-gradient layout, layers_per_block = 1).
  * what: 0 H[idx] | 1 Z[idx] | 2 saved sigmoid[idx] | 3 skip sum | 4 head activation[idx] | 5 logits |
- *       6 dL/d(final[idx] pre-activation) | 7 dL/d(skip sum) | 8 dL/du[idx] | 9 dL/dH[idx] | 10 max-abs slots */
+ *       6 dL/d(final[idx] pre-activation) | 7 dL/d(skip sum) | 8 dL/du[idx] | 9 dL/dH[idx] | 10 max-abs slots |
+ *       11 activated output of non-gated dilated conv i of block b, idx = b * (layers_per_block - 1) + i (any layout) */
 int wn_debug_ws_region(const wn_plan* p, int32_t B, int32_t T, int32_t what, int32_t idx, int64_t* off,
                        int64_t* len);
 /* the whole residual-block stack of a forward pass: one event pair per pass from the first block launch to

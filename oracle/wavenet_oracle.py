@@ -267,7 +267,8 @@ def dropout_keep_mask(n: int, key: int, rate: float) -> torch.Tensor:
 def layer_forward(x: torch.Tensor, layer_params: Sequence[torch.Tensor], *,
                   dilations: Sequence[int], activation_name: Optional[str],
                   residual: bool, has_skip: bool, cond: Optional[torch.Tensor] = None,
-                  drop: Optional[Tuple[float, int]] = None
+                  drop: Optional[Tuple[float, int]] = None,
+                  inner_branch: Optional[Sequence[torch.Tensor]] = None, kink_log: Optional[list] = None
                   ) -> Tuple[torch.Tensor, torch.Tensor]:
   """WaveNetLayer.call, src/layers.py:178-224 (dropout omitted: rate 0 in parity runs).
 
@@ -285,8 +286,15 @@ def layer_forward(x: torch.Tensor, layer_params: Sequence[torch.Tensor], *,
   for i, d in enumerate(dilations):
     kern, b = cur.take(2)
     h = causal_conv1d(h, kern, b, d)
-    if i < n - 1:
-      h = activation(h, activation_name)          # src/layers.py:66-74
+    if i < n - 1:                                 # src/layers.py:66-74
+      # (inner_branch: gradient comparisons only -- see activation_with_branch; kink_log collects (count, worst |pre|))
+      br_i = inner_branch[i] if inner_branch is not None else None
+      pre = h
+      h, nov = activation_with_branch(pre, activation_name, br_i)
+      if kink_log is not None and br_i is not None and activation_name in ('relu', 'leaky_relu'):
+        own = (pre >= 0) if activation_name == 'leaky_relu' else (pre > 0)
+        over = own != br_i.to(torch.bool)
+        kink_log.append((int(over.sum()), float(pre.detach()[over].abs().max()) if bool(over.any()) else 0.0, nov))
   kr, br = cur.take(2)
   if has_skip:
     ks, bs = cur.take(2)
@@ -355,7 +363,8 @@ def mapping_forward(cond: torch.Tensor, params: Sequence[torch.Tensor],
 def model_forward(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleConfig,
                   cond: Optional[torch.Tensor] = None, return_logits: bool = False,
                   return_intermediates: bool = False, dropout: Optional[Tuple[float, int, int]] = None,
-                  head_branch: Optional[Sequence[torch.Tensor]] = None):
+                  head_branch: Optional[Sequence[torch.Tensor]] = None,
+                  inner_branch: Optional[Sequence[Sequence[torch.Tensor]]] = None, kink_log: Optional[list] = None):
   """WaveNet.call, src/model.py:213-239.  x: (B,T,1); cond: (B, cond_inputs) or None.
 
   Returns probabilities for the categorical head (softmax activation on the last conv,
@@ -382,7 +391,8 @@ def model_forward(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleCo
       drop = (dropout[0], dropout_key(dropout[1], b, dropout[2]))
     h, sk = layer_forward(h, lp, dilations=dil[b * lpb:(b + 1) * lpb],
                           activation_name=cfg.activation, residual=cfg.use_residual,
-                          has_skip=cfg.skip_channels is not None, cond=c, drop=drop)
+                          has_skip=cfg.skip_channels is not None, cond=c, drop=drop,
+                          inner_branch=inner_branch[b] if inner_branch is not None else None, kink_log=kink_log)
     skips.append(sk)
     inter['h'].append(h)
   if cfg.use_skip:
@@ -557,7 +567,8 @@ def l2_penalty(params: Sequence[torch.Tensor], cfg: OracleConfig) -> torch.Tenso
 def loss_and_grads(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleConfig,
                    cond: Optional[torch.Tensor] = None, global_batch: Optional[int] = None,
                    n_replicas: int = 1, dropout: Optional[Tuple[float, int, int]] = None,
-                   head_branch: Optional[Sequence[torch.Tensor]] = None):
+                   head_branch: Optional[Sequence[torch.Tensor]] = None,
+                   inner_branch: Optional[Sequence[Sequence[torch.Tensor]]] = None, kink_log: Optional[list] = None):
   """Forward + loss + reverse-mode gradients of one replica's share of a train step.
 
   x: (B, T+1, 1).  inputs = x[:, :-1], target = prepare_target(x[:, 1:]) (src/model.py:
@@ -568,7 +579,8 @@ def loss_and_grads(x: torch.Tensor, params: Sequence[torch.Tensor], cfg: OracleC
   ps = [p.detach().clone().requires_grad_(True) for p in params]
   inputs, y_true = x[:, :-1, :], x[:, 1:, :]
   target = prepare_target(y_true, cfg)
-  pred = model_forward(inputs, ps, cfg, cond, dropout=dropout, head_branch=head_branch)
+  pred = model_forward(inputs, ps, cfg, cond, dropout=dropout, head_branch=head_branch, inner_branch=inner_branch,
+                       kink_log=kink_log)
   per = loss_fn(target, pred, cfg)                  # (B,T)
   Bg = x.shape[0] if global_batch is None else global_batch
   loss = per.sum() / Bg

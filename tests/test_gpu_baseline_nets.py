@@ -234,3 +234,62 @@ def test_30_block_generation_matches_oracle(name, queued):
     assert torch.equal(out[:, :upto], ref[:, :upto]), (name, queued, upto)
   else:
     assert (out[:, :upto] - ref[:, :upto]).abs().max().item() < ATOL_ACT, (name, queued, upto)
+
+
+# the reference's own default configuration (train.py:22-50): 5 WaveNetLayers of 5 stacked dilated convs each (only the
+# last one gated), 32 channels, gaussian mixture with 8 components on 16-bit audio, global conditioning through the
+# mapping net [8, 16, 32], dropout 0.1, dilation_bound 256, leaky_relu, head [128, 256], no separate skip width
+REFERENCE_DEFAULT = dict(blocks=5, layers_per_block=5, channels=32, dilation_bound=256, num_mixtures=8,
+                         sampling_function='gaussian', bits=16, conditioning='global', mapping_layers=[8, 16, 32],
+                         mapping_activation='leaky_relu', activation='leaky_relu', final_layers_channels=[128, 256],
+                         kernel_size=2)
+
+
+def test_reference_default_network_with_dropout(math_mode):
+  """train.py:22-50 as shipped: receptive field 768, 25 dilated convs, dropout ON (the mask is the product's stateless
+  hash of (seed, block, step, element), restated by the oracle -- TF's stream cannot be matched), one-hot(gender, 2)
+  condition (src/utils.py:46-49).  Forward (inference), loss and every parameter gradient of a training pass vs fp64."""
+  from wavenets_amd import WaveNet
+  kw = dict(REFERENCE_DEFAULT)
+  rate, seed = 0.1, 123
+  ocfg = O.OracleConfig(**kw, cond_inputs=2)
+  assert O.receptive_field(ocfg) == 768
+  params = O.init_params(ocfg, seed=9, bias_range=0.1)
+  model = WaveNet(**kw, dropout=rate, device=dev(), seed=seed)
+  model.build([(1, 8, 1), (1, 2)])
+  assert model.receptive_field == 768 and len(model.wavenet_blocks) == 5
+  model.set_weights([p.numpy() for p in params])
+  Bq, Tq = 3, 1200
+  x = O.synthetic_waveform(Bq, Tq + 1, seed=41)
+  cond = torch.nn.functional.one_hot(torch.tensor([0, 1, 1]), 2).float()
+  pd = [p.double() for p in params]
+  ref = O.model_forward(x[:, :-1].double(), pd, ocfg, cond.double())
+  out = model((x[:, :-1].to(dev()), cond.to(dev()))).cpu().double()
+  assert (out - ref).abs().max().item() < ATOL_ACT
+  n_head = n_inner = 0
+  for step in (1, 2):
+    loss, _, _ = model.loss_and_grads((x.to(dev()), cond.to(dev())))
+    torch.cuda.synchronize()
+    # leaky_relu's derivative jumps at 0: where the ORACLE's own fp64 pre-activation lies within KINK_TOL of 0 it takes the
+    # side the product took (O.activation_with_branch) -- for the two head activations and the 20 non-gated dilated convs
+    # (src/layers.py:66-74, src/model.py:105-111).  The overrides are counted and bounded below.
+    head_branch = [model.training_intermediate(4, i, Bq, Tq).cpu().reshape(Bq, Tq, -1) >= 0 for i in range(2)]
+    inner_branch = [[model.training_intermediate(11, b * 4 + i, Bq, Tq).cpu().reshape(Bq, Tq, -1) >= 0 for i in range(4)]
+                    for b in range(5)]
+    klog = []
+    loss_ref, _, grads_ref, _ = O.loss_and_grads(x.double(), pd, ocfg, cond.double(), dropout=(rate, seed, step),
+                                                 head_branch=head_branch, inner_branch=inner_branch, kink_log=klog)
+    assert len(klog) == 20
+    for cnt, worst, nov in klog:
+      assert cnt == nov and worst < O.KINK_TOL, (cnt, nov, worst)      # every disagreement lies inside the undecided band
+    n_inner += sum(c for c, _, _ in klog)
+    with torch.no_grad():
+      _, inter = O.model_forward(x[:, :-1].double(), pd, ocfg, cond.double(), return_intermediates=True,
+                                 dropout=(rate, seed, step), head_branch=head_branch, inner_branch=inner_branch)
+    n_head += inter['kink_overrides']
+    assert abs(loss[0].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item())), (step, loss[0].item(), loss_ref.item())
+    for n, g, r in zip(model.variable_names, model.gradients(), grads_ref):
+      scale = max(r.abs().max().item(), 1e-6)
+      e = (g.cpu().double() - r).abs().max().item()
+      assert e < 1e-4 * scale + 1e-7, (n, step, e, scale)
+  assert n_inner <= 8 and n_head <= 8, (n_inner, n_head)

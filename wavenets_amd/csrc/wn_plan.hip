@@ -1266,6 +1266,12 @@ extern "C" int wn_debug_ws_region(const wn_plan* p, int32_t B, int32_t T, int32_
     case 8: if (in(L.GU.size())) { *off = L.GU[idx]; *len = rows * 2 * p->D; } break;
     case 9: if (in(L.GH.size())) { *off = L.GH[idx]; *len = rows * p->R; } break;
     case 10: *off = L.absmax; *len = L.n_absmax; break;
+    case 11: {                           // activated output of non-gated conv i of block b (idx = b * (LPB - 1) + i), depth > 1
+      const int inner = p->LPB - 1;
+      if (inner > 0 && idx >= 0 && idx < p->N * inner && (size_t)(idx / inner) < L.P.size() &&
+          (size_t)(idx % inner) < L.P[idx / inner].size()) { *off = L.P[idx / inner][idx % inner]; *len = rows * p->D; }
+      break;
+    }
     default: break;
   }
   if (*off < 0) { wn_set_error("ws_region: no such region (%d, %d)", what, idx); return WN_E_INVALID; }
