@@ -172,7 +172,7 @@ def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmu
     S_eff = kw.get('skip_channels') or R
     stack_bytes = nblk * 4.0 * B * T * (2 * R + S_eff)
     t_stack = stack_ms + prep_ms
-    res[name] = {'workload': desc, 'ms_per_step': dt * 1e3, 'samples_per_s': B * T / dt, 'steps': steps,
+    res[name] = {'workload': desc, 'kernel_families': m.kernel_report(), 'ms_per_step': dt * 1e3, 'samples_per_s': B * T / dt, 'steps': steps,
                  'final_loss': logs['loss'],
                  'stack_fwd': {'t_stack_fwd_ms': t_stack, 't_fold_prep_ms': prep_ms, 'passes_timed': n_s,
                                'algorithmic_bytes': stack_bytes,
@@ -321,6 +321,7 @@ def main():
   # roofline inputs from EXTRA, untimed steps: HIP events on the launch stream around the block chain (per-launch
   # average of the fused block kernel), around the whole stack (first block launch -> end of the folded contraction) and
   # around the fold's per-pass weight-space preparation (V = W_s W_f0 and its fp16 images), which runs before the stack
+  kernel_families = model.kernel_report()
   n_prof = max(3, min(args.steps, 10))
   n_l, avg_ms, n_s, stack_ms, prep_ms = stack_profile(model, x, n_prof, nblk)
   if world > 1:
@@ -420,7 +421,7 @@ def main():
         'math': 'fp32 tensors; contractions as fp16 hi/lo split, 3 products on v_mfma_f32_32x32x16_f16 with fp32 '
                 'accumulate (|err| <= 6e-7 on O(1) results, parity-tested at 1e-4); exact-fp32 MFMA selectable',
         'exact_fp32_mfma': {'ms_per_step': dt_fp32 * 1e3, 'value': world * B * T / dt_fp32},
-        'phases_ms': phases,
+        'phases_ms': phases, 'kernel_families': kernel_families,
         'config': {'workload': 'configs[1]: 30-layer (3x10) mu-law-256 WaveNet, 64 residual / 256 skip ch, '
                                f'head [128,256], batch {B}x{T} per GPU, full train step '
                                '(fwd+loss+bwd+allreduce+clipnorm-Adam+sample_waveform draw+MSE metric, as train.py:225-228 compiles it)',

@@ -75,7 +75,13 @@ typedef struct wn_plan wn_plan;
 
 const char* wn_last_error_string(void);
 
-/* ---- plan: immutable launch metadata (WaveNet.__init__ + build, src/model.py:14-211) ---- */
+/* ---- plan (WaveNet.__init__ + build, src/model.py:14-211).  The network description inside a plan (shapes, dilation
+ * schedule, tensor table, image layouts) is immutable after wn_plan_create.  A plan ALSO carries per-caller launch state
+ * that the calls below set and the entry points read: the dropout counter (wn_plan_set_dropout), the armed step-sample
+ * pointer (wn_plan_arm_step_sample), the phase selection (wn_plan_set_train_phases), its side stream / events and the
+ * measurement hooks (wn_prof_*, wn_stack_prof_*, wn_phase_*), plus device-side job tables cached per (B, T).  A plan
+ * therefore serves ONE stream / one thread at a time; callers that drive several streams create one plan per stream
+ * (plans are cheap: no device memory besides the job tables). ---- */
 wn_plan* wn_plan_create(const wn_config* cfg);          /* NULL on error */
 void wn_plan_destroy(wn_plan* p);
 int64_t wn_plan_param_count(const wn_plan* p);
@@ -107,6 +113,8 @@ int wn_debug_set(int key, int value);     /* kernel-variant switches of the CALL
 int wn_debug_value(int key);              /* current value of a switch in the calling thread */
 int wn_debug_gen_ts(unsigned long long* out_96); /* switch 24: s_memtime stamps [role 3][block 4][phase 8] of the last
                                              generation chain launch (profiling hook; -1 if none was taken) */
+/* one line naming the kernel family every phase of a pass selects for this plan under the calling thread's switches */
+int wn_plan_describe(const wn_plan* p, char* buf, int32_t len);
 int wn_prof_enable(wn_plan* p, int32_t max_launches);
 int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms);
 /* test / diagnosis hook: float offset and length, inside the caller's TRAINING workspace for (B, T), of an

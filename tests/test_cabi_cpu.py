@@ -143,3 +143,28 @@ def test_layer_desc_param_count(lib):
   assert lib.wn_layer_param_count(C.byref(d)) == 37312
   assert lib.wn_layer_workspace_floats(C.byref(d), 2, 1000) > 0
   assert lib.wn_layer_saved_floats(C.byref(d), 2, 1000) >= 2 * 1000 * (64 + 64)   # sigmoid + gated activation per row
+
+
+def test_plan_describe_names_the_kernel_family_of_every_phase():
+  """The fast paths are shape-specialised; wn_plan_describe says which family a plan takes (no silent slow path)."""
+  lib = _lib.lib()
+
+  def describe(s, **kw):
+    p = C.c_void_p(_plan(lib, s, **kw))
+    buf = C.create_string_buffer(2048)
+    assert lib.wn_plan_describe(p, buf, 2048) == 0
+    lib.wn_plan_destroy(p)
+    return buf.value.decode()
+  base = dict(blocks=30, dilation_bound=1024, skip_channels=256, final_layers_channels=[128, 256], activation='leaky_relu')
+  c1 = describe(_cfg(channels=64, **base))                                   # BASELINE configs[1]
+  assert 'wn_layer_fwd_f16_kernel' in c1 and 'wn_bwd_pair_kernel' in c1 and 'wn_wgrad_layer_kernel' in c1 and 'folded' in c1
+  c3 = describe(_cfg(channels=128, num_mixtures=10, sampling_function='logistic', bits=16, **base))     # configs[3]
+  assert 'wn_layer_fwd_s128_kernel' in c3 and 'wn_wgrad_pair_kernel' in c3 and 'folded' in c3
+  d = describe(_cfg(blocks=5, layers_per_block=5, dilation_bound=256, num_mixtures=8, sampling_function='gaussian', bits=16,
+                    final_layers_channels=[128, 256], activation='leaky_relu'))   # the reference's default (train.py:22-50)
+  assert 'layers_per_block > 1' in d
+  lib.wn_debug_set(1, 1)
+  try:
+    assert 'exact fp32' in describe(_cfg(channels=64, **base))
+  finally:
+    lib.wn_debug_set(1, 0)

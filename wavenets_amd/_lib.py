@@ -73,6 +73,7 @@ _SIGS = {
     'wn_debug_gen_ts': (C.c_int, [_P]),
     'wn_plan_set_dropout': (C.c_int, [_P, C.c_float, C.c_uint64, C.c_uint64]),
     'wn_dropout_key_for': (C.c_uint32, [C.c_uint64, C.c_int32, C.c_uint64]),
+    'wn_plan_describe': (C.c_int, [_P, C.c_char_p, C.c_int32]),
     'wn_prof_enable': (C.c_int, [_P, C.c_int32]),
     'wn_prof_read': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     'wn_debug_ws_region': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),

@@ -1247,6 +1247,46 @@ extern "C" int64_t wn_plan_workspace_floats(const wn_plan* p, int32_t B, int32_t
 //   what: 0 block input H[idx] (idx 0..N) | 1 gated activations Z of block idx | 2 saved sigmoid of block idx |
 //         3 skip sum | 4 head activation idx | 5 logits | 6 d loss / d (final layer idx output, pre-activation) |
 //         7 d loss / d skip sum | 8 d loss / d u of block idx ([rows][2D]) | 9 d loss / d H[idx] | 10 running max-abs slots
+// Which kernel family each phase of a pass selects for this plan under the calling thread's switches -- the fast paths are
+// shape-specialised, everything else takes composed paths that are several times slower; this makes
+// the choice visible (WaveNet.kernel_report(), bench.py "kernel_families", WN_LOG_KERNELS=1 prints it once per plan).
+extern "C" int wn_plan_describe(const wn_plan* p, char* buf, int32_t len) {
+  if (!p || !buf || len < 1) return WN_E_INVALID;
+  const bool exact = wn_debug_get(1) == 1;
+  const char* fwd;
+  if (p->LPB > 1) fwd = "composed per conv (rows GEMM fp32 + fused fp32 kernel for the gated conv where the shape allows)";
+  else if (!exact && p->fused16_ok) fwd = "fused split-precision block kernel, weights LDS-resident (wn_layer_fwd_f16_kernel)";
+  else if (!exact && !p->blocks.empty() && p->blocks[0].f16nat >= 0 && wn_debug_get(11) == 0)
+    fwd = "fused split-precision block kernel, weights streamed through an LDS ring (wn_layer_fwd_s128_kernel)";
+  else if (!exact && !p->blocks.empty() && p->blocks[0].f16gate >= 0 && wn_debug_get(11) != 1)
+    fwd = "two split-precision contractions per block (gated conv + gate, 1x1 + residual)";
+  else if (p->fused_ok) fwd = "fused exact-fp32 block kernel (wn_layer_fwd_kernel)";
+  else fwd = "composed: rows GEMM -> gate kernel -> rows GEMM";
+  const bool fold = fold_ok(p);
+  const bool deferred = deferred_wgrad(p);
+  const char* bwd;
+  if (!deferred) bwd = "per-block composed backward with per-call weight gradients (layers_per_block > 1)";
+  else if (fold && p->N >= 2 && wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1)
+    bwd = "two products per launch (wn_bwd_pair_kernel: g_x(b+1) and g_u(b))";
+  else if (!exact) bwd = "two split-precision rows contractions per block (g_u with the gate derivative, g_x)";
+  else bwd = "two exact-fp32 rows contractions per block";
+  const char* wg;
+  if (!deferred) wg = "per-call split-K products (wn_wgrad_kernel) + reduces";
+  else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(8) != 1 && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R)
+    wg = "one workgroup per (block, utterance, time range) for dW_d, db_d, dW_r, db_r (wn_wgrad_layer_kernel)";
+  else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(13) != 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D &&
+           wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 && wn_wgrad_pair_kind(p->D, p->R) == 2)
+    wg = "staged pair jobs, three per block (wn_wgrad_pair_kernel)";
+  else wg = "generic batched job table (wn_wgrad_batched_kernel)";
+  snprintf(buf, (size_t)len,
+           "math: %s | block forward: %s | skip path: %s | backward data: %s | block weight gradients: %s",
+           exact ? "exact fp32 MFMA" : "fp16 hi|lo split, 3 products, fp32 accumulate", fwd,
+           fold ? "folded into the head's first conv (V = W_s W_f0, training / inference / generation)"
+                : (p->c.use_skip ? "one contraction over all blocks' gated activations, then the head" : "none (use_skip False)"),
+           bwd, wg);
+  return WN_OK;
+}
+
 extern "C" int wn_debug_ws_region(const wn_plan* p, int32_t B, int32_t T, int32_t what, int32_t idx, int64_t* off,
                                   int64_t* len) {
   if (!p || !off || !len || B < 1 || T < 1) return WN_E_INVALID;

@@ -240,6 +240,19 @@ class WaveNet(torch.nn.Module):
     except Exception:  # interpreter shutdown
       pass
 
+  def kernel_report(self) -> str:
+    """Which kernel family each phase selects for this network (the fast paths are shape-specialised)."""
+    buf = C.create_string_buffer(2048)
+    _lib.check(_lib.lib().wn_plan_describe(self._plan, buf, 2048))
+    return buf.value.decode()
+
+  def _log_kernels_once(self):
+    import os
+    import sys
+    if not getattr(self, '_kernels_logged', False) and os.environ.get('WN_LOG_KERNELS'):
+      self._kernels_logged = True
+      print('[wavenets_amd] ' + self.kernel_report(), file=sys.stderr)
+
   # ------------------------------------------------------------------ weights
   def _tensor(self, name):
     i = self._names.index(name)
@@ -442,6 +455,7 @@ class WaveNet(torch.nn.Module):
     if n_replicas is None:
       n_replicas = world
     L = _lib.lib()
+    self._log_kernels_once()
     ws = self._workspace('train', L.wn_plan_workspace_floats(self._plan, B, T, 1))
     # train_step keeps {loss, reg_loss} in the gradient bucket's tail (one all-reduce); other callers get their own tensor
     loss = self._grad_bucket[self.flat_params.numel():] if _loss_in_bucket else \
