@@ -32,6 +32,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   14  = 1: global conditioning per block (no single contraction over all blocks)
 //   15  = 1: last block's backward without the (zero) output gradient: one-segment product on the fp32 kernel
 //   16  = 2: 128-channel blocks: both taps of the gated conv's weight gradient in one job (du read once; spills, slower)
+//   17  = 1: stacks deeper than 1 (layers_per_block > 1): per-call weight gradients instead of the batched job table
+//   18  = 1: stacks deeper than 1: the batched weight gradients on the split-precision job kernel (inner gradients unscaled: A/B only)
 //   19  = 1: head layers' weight gradients on the generic job table (no staged pair jobs)
 //   20  = 1: input conv's weight gradients on the generic job table (no dedicated reduction kernel)
 //   21  = 1: training passes keep the skip sum and the head's first conv as two steps (no folded V = W_s W_f0 contraction)

@@ -592,11 +592,12 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_batched_kernel(const WnWgJob*
 }
 
 int wn_launch_wgrad_batched(const WnWgJob* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
-                            int splits_per_b, hipStream_t s) {
+                            int splits_per_b, hipStream_t s, bool exact_fp32) {
   if (njobs <= 0) return WN_OK;
   const int nsplit = B * splits_per_b;
-  // knob 1 = 1 forces exact-fp32 MFMA; knob 3 = 1 keeps the weight gradients alone on fp32
-  if (wn_debug_get(1) == 1 || wn_debug_get(3) == 1)
+  // knob 1 = 1 forces exact-fp32 MFMA; knob 3 = 1 keeps the weight gradients alone on fp32; exact_fp32: gradient operands
+  // without a max-abs slot (inner convs of stacks deeper than 1)
+  if (exact_fp32 || wn_debug_get(1) == 1 || wn_debug_get(3) == 1)
     hipLaunchKernelGGL(wn_wgrad_batched_kernel<false>, dim3((nsplit + 3) / 4, njobs), dim3(256), 0, s, d_jobs, ws, slab, P,
                        B, T, splits_per_b);
   else

@@ -134,7 +134,7 @@ int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64
 int wn_wgrad_tile_k();
 int wn_wgrad_tile_n();
 int wn_launch_wgrad_batched(const WnWgJob* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
-                            int splits_per_b, hipStream_t s);
+                            int splits_per_b, hipStream_t s, bool exact_fp32 = false);
 int wn_launch_reduce_table(const float* slab, int nsplit, int64_t P, float* out, const WnTensorDesc* d_table,
                            int n, hipStream_t s);
 // out[(k / seg_len) * seg_stride + (k % seg_len) * N + n] (+)= sum_s slab[s][k][n]

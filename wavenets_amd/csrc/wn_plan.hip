@@ -260,6 +260,7 @@ struct WsLayout {
   std::vector<std::vector<int64_t>> P;  // per block: outputs of the non-gated convs (depth > 1)
   int64_t Z;                            // [rows][N*Dp]
   std::vector<int64_t> AG;              // per block [rows][D] saved sigmoid (training)
+  std::vector<std::vector<int64_t>> GP; // per block, per non-gated conv: [rows][D] gradient of its pre-activation output
   int64_t U;                            // [rows][2D] scratch of the composed path / g_u
   int64_t O;                            // [rows][R] pre-residual output scratch
   int64_t skipsum;                      // [rows][Hin]
@@ -302,9 +303,10 @@ int64_t slab_need(int B, int T, int K, int N) {
   return (int64_t)B * sp * ((int64_t)K * N + N);
 }
 
-// The batched weight-gradient path needs depth-1 blocks (every dW operand is then a whole saved
-// tensor); deeper stacks use the per-call path.
-bool deferred_wgrad(const wn_plan* p) { return p->LPB == 1; }
+// The batched weight-gradient path: every dW operand is a whole saved tensor.
+// (round 3: stacks deeper than 1 too -- every conv's input and output gradient is kept, the weight gradients of all
+//  convs of the step are one launch of the generic job table; knob 17 = 1: the per-call path for them)
+bool deferred_wgrad(const wn_plan* p) { return p->LPB == 1 || wn_debug_get(17) != 1; }
 
 int jobs_for(int K, int N) {
   return ((K + wn_wgrad_tile_k() - 1) / wn_wgrad_tile_k()) * ((N + wn_wgrad_tile_n() - 1) / wn_wgrad_tile_n());
@@ -314,6 +316,7 @@ int count_jobs(const wn_plan* p) {
   int n = p->KS * jobs_for(1, p->R);
   for (const BlockInfo& b : p->blocks) {
     n += p->KS * jobs_for(p->R, 2 * p->D) + jobs_for(p->D, p->R);
+    for (int i = 0; i + 1 < p->LPB; ++i) n += p->KS * jobs_for(i == 0 ? p->R : p->D, p->D);
     if (b.has_skip && p->c.use_skip) n += jobs_for(p->D, p->S);
   }
   for (const ConvInfo& c : p->finals) n += jobs_for(c.cin, c.cout);
@@ -429,6 +432,10 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     L.islab = 0; L.isplits = 0;
     if (deferred_wgrad(p)) {
       for (int b = 0; b < p->N; ++b) L.GU.push_back(cv.take(rows * 2 * p->D));
+      // depth > 1: gradient w.r.t. the pre-activation output of every non-gated conv (operand of its weight gradient)
+      L.GP.assign(p->N, std::vector<int64_t>());
+      for (int b = 0; b < p->N; ++b)
+        for (int i = 0; i + 1 < p->LPB; ++i) L.GP[b].push_back(cv.take(rows * p->D));
       for (int b = 0; b <= p->N; ++b) L.GH.push_back(cv.take(rows * p->R));
       if (p->S == 0) for (int b = 0; b < p->N; ++b) L.GO.push_back(cv.take(rows * p->R));
       for (size_t i = 0; i < p->finals.size(); ++i) L.GF.push_back(cv.take(rows * p->finals[i].cout));
@@ -720,6 +727,7 @@ struct BlockGrads {
   float* g_o_tmp;           // [rows][R] scratch (needed when S == 0 and both grads exist)
   float* g_u;               // [rows][2D] scratch
   float* g_p;               // [2][rows][D] scratch (depth > 1), halves used alternately
+  float* g_pi[16];          // deferred weight gradients: where the gradient of conv i's pre-activation output is KEPT, or null
   float* g_x;               // [rows][Cin] out (may be null when not needed)
   float* g_cond;            // [rows][Cc] out or null
   float* dWd[16]; float* dbd[16];
@@ -828,7 +836,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
       gm.seg(gcur, gc, gc, -(k.KS - 1 - t) * k.dil[i], k.Bd[i] + t * k.Bd_stride[i]);
     if (i > 0) {
       // output is the gradient w.r.t. P[i-1] (post-activation) -> fold act' in
-      float* dst = g.g_p + (int64_t)((i & 1) ? 0 : rows * k.D);
+      float* dst = g.g_pi[i - 1] ? g.g_pi[i - 1] : g.g_p + (int64_t)((i & 1) ? 0 : rows * k.D);
       rc = gm.dact(f.P[i - 1], k.D, k.act).run(dst, k.D, s);
       if (rc) return rc;
       gcur = dst; gc = k.D;
@@ -1266,12 +1274,14 @@ extern "C" int wn_plan_describe(const wn_plan* p, char* buf, int32_t len) {
   const bool deferred = deferred_wgrad(p);
   const char* bwd;
   if (!deferred) bwd = "per-block composed backward with per-call weight gradients (layers_per_block > 1)";
+  else if (p->LPB > 1) bwd = "per-block composed backward, one rows contraction per conv of the stack (layers_per_block > 1)";
   else if (fold && p->N >= 2 && wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1)
     bwd = "two products per launch (wn_bwd_pair_kernel: g_x(b+1) and g_u(b))";
   else if (!exact) bwd = "two split-precision rows contractions per block (g_u with the gate derivative, g_x)";
   else bwd = "two exact-fp32 rows contractions per block";
   const char* wg;
   if (!deferred) wg = "per-call split-K products (wn_wgrad_kernel) + reduces";
+  else if (p->LPB > 1) wg = "generic batched job table in exact fp32, every conv of every stack in one launch (wn_wgrad_batched_kernel)";
   else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(8) != 1 && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R)
     wg = "one workgroup per (block, utterance, time range) for dW_d, db_d, dW_r, db_r (wn_wgrad_layer_kernel)";
   else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(13) != 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D &&
@@ -1629,10 +1639,10 @@ bool skip_kernel_ok(const wn_plan* p) {
 int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool skipk = skip_kernel_ok(p);
   // knob 8 = 1 keeps the per-block weight gradients on the generic job table
-  const bool layerk = wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1 &&
+  const bool layerk = p->LPB == 1 && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1 &&
                       wn_debug_get(3) != 1 && wn_debug_get(8) != 1;
   // knob 13 = 1 keeps them on the generic job table
-  const bool pairk = !layerk && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
+  const bool pairk = !layerk && p->LPB == 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
                      wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
                      wn_debug_get(13) != 1;
   // knob 16 = 2: both taps of a block's gated conv as ONE job (du read once).  Measured slower at configs[3] (22.1 vs
@@ -1705,15 +1715,25 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       w.gmax_off = p->S == 0 ? am_skip : am_GH(b + 1);
       pairs[2].push_back(w);
     } else {
-    for (int t = 0; t < p->KS; ++t)
-      add_jobs(jobs, p->drop_rate > 0.f ? L.XD[b] : L.H[b], p->R, p->R, (p->KS - 1 - t) * c.dil, L.GU[b], 2 * p->D, 2 * p->D,
-               p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D,
-               t == p->KS - 1 ? p->tensors[c.bias_t].off : -1, am_GU(b));
+    // the dilated stack: conv i reads H[b] (or its dropped copy) / the activated output of conv i - 1; its output gradient
+    // is GP[b][i], or GU[b] for the last, gated conv (2D wide).  (Inner gradients have no max-abs slot: stacks deeper
+    // than 1 run this table in exact fp32, see the launch.)
+    for (int i = 0; i < p->LPB; ++i) {
+      const ConvInfo& ci = bi.dil[i];
+      const bool lastc = i == p->LPB - 1;
+      const int64_t xo = i == 0 ? (p->drop_rate > 0.f ? L.XD[b] : L.H[b]) : L.P[b][i - 1];
+      const int kc = i == 0 ? p->R : p->D, nc = lastc ? 2 * p->D : p->D;
+      for (int t = 0; t < p->KS; ++t)
+        add_jobs(jobs, xo, kc, kc, (p->KS - 1 - t) * ci.dil, lastc ? L.GU[b] : L.GP[b][i], nc, nc,
+                 p->tensors[ci.kernel_t].off + (int64_t)t * kc * nc,
+                 t == p->KS - 1 ? p->tensors[ci.bias_t].off : -1, lastc ? am_GU(b) : -1);
+      if (!lastc) { cover(ci.kernel_t); cover(ci.bias_t); }
+    }
     // S == 0: g_o = g_xout + g_skip (or a copy of g_skip): bounded by twice the larger max-abs -> no slot
     add_jobs(jobs, zoff, p->Dp, p->D, 0, p->S == 0 ? L.GO[b] : L.GH[b + 1], p->R, p->R,
              p->tensors[bi.conv1.kernel_t].off, p->tensors[bi.conv1.bias_t].off, p->S == 0 ? am_skip : am_GH(b + 1));
     }
-    cover(c.kernel_t); cover(c.bias_t);
+    cover(bi.dil.back().kernel_t); cover(bi.dil.back().bias_t);
     cover(bi.conv1.kernel_t); cover(bi.conv1.bias_t);
     if (bi.has_skip && p->c.use_skip && !fold) {     // (folded: dW_s, db_s come out of M, see the weight-gradient phase)
       if (!skipk)
@@ -2034,11 +2054,13 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       BlockBufs f;
       memset(&f, 0, sizeof(f));
       f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
+      for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
       f.AG = ws + L.AG[b];
       f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;
       BlockGrads bg;
       memset(&bg, 0, sizeof(bg));
       bg.defer = true;
+      for (int i = 0; i + 1 < p->LPB; ++i) bg.g_pi[i] = ws + L.GP[b][i];
       if (p->drop_rate > 0.f) {
         bg.drop_rate = p->drop_rate; bg.drop_key = wn_dropout_key(p->drop_seed, b, p->drop_step); bg.g_xd = ws + L.gxd;
       }
@@ -2102,7 +2124,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     }
     const bool head_own = L.hsplits > 0 && (p->head_first < p->njobs || p->jobs_headpairs);
     rc = wn_launch_wgrad_batched(p->d_jobs, head_own ? p->head_first : p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits,
-                                 fork ? p->side : s);
+                                 fork ? p->side : s, p->LPB > 1 && wn_debug_get(18) != 1);
     if (rc) return rc;
     if (head_own) {
       // job and coverage offsets are offsets into the flat parameter buffer: the compact slab is addressed
@@ -2169,10 +2191,10 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     if (cond_batched) {
       const int D2 = 2 * p->D;
       const BlockInfo& b0 = p->blocks[0];
-      const int64_t dst = p->N > 1 ? p->tensors[p->blocks[1].dil[0].bias_t].off - p->tensors[b0.dil[0].bias_t].off : 0;
+      const int64_t dst = p->N > 1 ? p->tensors[p->blocks[1].dil.back().bias_t].off - p->tensors[b0.dil.back().bias_t].off : 0;
       const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.kernel_t].off - p->tensors[b0.conv_cond.kernel_t].off : 0;
       const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.bias_t].off - p->tensors[b0.conv_cond.bias_t].off : 0;
-      rc = wn_launch_cond_gather(ws + L.bslab, p->nparams, L.bsplits, p->tensors[b0.dil[0].bias_t].off, dst, B, p->N, D2,
+      rc = wn_launch_cond_gather(ws + L.bslab, p->nparams, L.bsplits, p->tensors[b0.dil.back().bias_t].off, dst, B, p->N, D2,
                                  ws + L.cbt, s);
       if (rc) return rc;
       rc = Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.cbt, p->N * D2, p->N * D2, 0, fragbase + p->frag_condB).run(ws + L.g_m0, p->Cc, s);
