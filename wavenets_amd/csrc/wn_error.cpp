@@ -31,7 +31,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   13  = 1: 128-channel per-block weight gradients on the generic job table (no wn_wgrad_pair_kernel)
 //   14  = 1: global conditioning per block (no single contraction over all blocks)
 //   15  = 1: last block's backward without the (zero) output gradient: one-segment product on the fp32 kernel
-//   16  = 2: 128-channel blocks: both taps of the gated conv's weight gradient in one job (du read once; spills, slower)
+//   16  = 1: 128-channel blocks: one staged weight-gradient job per tap of the gated conv (du read twice) instead of the
+//       transposed-LDS-read kernel with both taps (wn_wgrad_tr.hip); = 2: the staged kernel with both taps (spills, slower)
 //   17  = 1: stacks deeper than 1 (layers_per_block > 1): per-call weight gradients instead of the batched job table
 //   18  = 1: stacks deeper than 1: the batched weight gradients on the split-precision job kernel (inner gradients unscaled: A/B only)
 //   19  = 1: head layers' weight gradients on the generic job table (no staged pair jobs)

@@ -109,6 +109,11 @@ struct WnWgPair {
 int wn_wgrad_pair_kind(int K, int N);
 int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
                           int splits_per_b, hipStream_t s);
+// both taps of a 128 -> 256 kernel-size-2 convolution's weight gradient from one read of G, transposition in the LDS read
+// (wn_wgrad_tr.hip); jobs: x_off, g_off, shift = dilation, w_off = tap 0's offset, b_off, gmax_off
+int wn_wgrad_tr_kind(int K, int N, int taps);
+int wn_launch_wgrad_tr(int kind, const WnWgPair* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
+                       int splits_per_b, hipStream_t s);
 // two products of the backward-data chain per launch: g_x(b+1) and, from it in registers, g_u(b) (wn_bwd_pair.hip)
 struct WnBwdPairArgs {
   const float* gu_in;    // g_u(b+1) [rows][2D]

@@ -21,6 +21,11 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+#ifdef WN_S128_DIAG
+// phase stamps of the timing build (DIAG & 64): [workgroup][wave][pass 0..1][phase 0..9], read by wn_debug_s128_ts
+__device__ unsigned long long wn_s128_ts[512 * 4 * 2 * 10];
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
@@ -142,6 +147,12 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
   };
   auto next_slot = [](int s) { return s + 1 == C::NBUF ? 0 : s + 1; };
 
+#ifdef WN_S128_DIAG
+#define S128_TS(k) do { if constexpr ((DIAG & 64) != 0) { if (lane == 0 && pass < 2 && blockIdx.x < 512) \
+  wn_s128_ts[((blockIdx.x * 4 + wave) * 2 + pass) * 10 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define S128_TS(k) do { } while (0)
+#endif
   float wmax = 0.f;
   __syncthreads();                                     // bias table
   // the first two chunks of the stream
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     // for chunk c + 2 go into the ring slot chunk c - 1 used, hence after the barrier every wave reaches once it has
     // finished chunk c - 1.  vmcnt retires loads in order, so "at most N outstanding" with N = the LOADS issued after
     // the ones chunk c needs means those have landed; stores in between only make the wait conservative.
+    S128_TS(0);
     xdma(0);
     xdma(1);
     int slot = slot0;                                  // ring slot of chunk c, advanced per step (scalar)
@@ -216,6 +228,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
       constexpr int nyl = c == 0 ? PX : PT + (c + 1 < NC1 ? PX : 0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nyl) : "memory");
       asm volatile("s_barrier" ::: "memory");
+      if constexpr (c == 0) S128_TS(1);
+      if constexpr (c == 8) S128_TS(2);
       const int slot2 = next_slot(next_slot(slot));
       const h8* wl = reinterpret_cast<const h8*>(smem + slot * C::CHUNK) + lane;
       const f32x4* xl = reinterpret_cast<const f32x4*>(xbuf + (c % C::XB) * C::XBUF) + lane;
@@ -248,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
       slot = next_slot(slot);
     });
 
+    S128_TS(3);
     // =================== gate (in place): u[j] -> z, u[j + 4] -> sigmoid ===================
 #pragma unroll
     for (int j = 0; j < C::D32; ++j)
@@ -257,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
         u[j + C::D32][r] = sg;
         u[j][r] = ((DIAG & 8) ? u[j][r] : wn_tanh_fast(u[j][r])) * sg;
       }
+    S128_TS(4);
     // lane offset inside a group of eight rows (row stride 512 B for the R / D wide tensors, ldz * 4 for z)
     const unsigned voff128 = (unsigned)(lane >> 3) * 512u + (unsigned)(lane & 7) * 16u;
     auto store_sig = [&](auto full_) {
@@ -279,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     };
     if (rows_valid == 32) { store_sig(std::true_type{}); store_z(std::true_type{}); }
     else if (rows_valid > 0) { store_sig(std::false_type{}); store_z(std::false_type{}); }
+    S128_TS(5);
     // The residual (x itself, or a separate tensor: dropout feeds the conv a dropped copy, queued generation ring rows) is
     // re-read here, ahead of the 1x1 whose products hide part of its latency, in the STORE layout of x_out (lane = 16 bytes of a
     // 128-byte row segment, 8 rows per instruction: whole cache lines) and added on the way out.  Keeping the newest tap's
@@ -300,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
           xr[j][i] = *(const __attribute__((address_space(1))) f32x4*)(rbase + 128 * j + roff);
         }
     }
+    S128_TS(6);
     // =================== 1x1 residual conv: NC2 chunks of two k-steps; B operand = the z tiles as they stand ===================
     f32x16 o[C::R32];
 #pragma unroll
@@ -317,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
       constexpr int nyl = PT + (cc < 2 ? NRES : 0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nyl) : "memory");
       asm volatile("s_barrier" ::: "memory");
+      if constexpr (cc == 0) S128_TS(7);
       const int slot2 = next_slot(next_slot(slot));
       const h8* wl = reinterpret_cast<const h8*>(smem + slot * C::CHUNK) + lane;
       h8 fr[2][2];
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
       slot = next_slot(slot);
     });
     slot0 = slot;                                      // NCH % NBUF != 0: the next tile starts where this one ended
+    S128_TS(8);
 
     // =================== residual, range guard, x_out ===================
     auto store_out = [&](auto full_) {
@@ -380,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     };
     if (rows_valid == 32) store_out(std::true_type{});
     else if (rows_valid > 0) store_out(std::false_type{});
+    S128_TS(9);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead chunks land before the LDS is given back
   if (a.absmax_out) {
@@ -411,7 +432,7 @@ int wn_launch_layer_fwd_s128(const WnLayerFwdArgs& a, hipStream_t s) {
   if (resmode == 1 && save && wn_debug_get(29) != 0) {   // timing ablations of the training form (tools/time_s128.py)
 #define WN_S128_D(D_) case D_: hipLaunchKernelGGL((wn_layer_fwd_s128_kernel<2, 1, true, D_>), dim3((unsigned)gx), dim3(256), 0, s, a); break;
     switch (wn_debug_get(29)) {
-      WN_S128_D(1) WN_S128_D(2) WN_S128_D(4) WN_S128_D(8) WN_S128_D(16) WN_S128_D(32) WN_S128_D(19) WN_S128_D(12) WN_S128_D(51) WN_S128_D(63)
+      WN_S128_D(1) WN_S128_D(2) WN_S128_D(4) WN_S128_D(8) WN_S128_D(16) WN_S128_D(32) WN_S128_D(19) WN_S128_D(12) WN_S128_D(51) WN_S128_D(63) WN_S128_D(64)
       default: wn_set_error("layer_fwd_s128: no such ablation"); return WN_E_INVALID;
     }
 #undef WN_S128_D
@@ -425,3 +446,9 @@ int wn_launch_layer_fwd_s128(const WnLayerFwdArgs& a, hipStream_t s) {
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }
+
+#ifdef WN_S128_DIAG
+extern "C" int wn_debug_s128_ts(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(wn_s128_ts), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -100,7 +100,7 @@ struct wn_plan {
   WnWgPair* d_pairs = nullptr;
   int pair_first[3] = {0, 0, 0}, pair_count[3] = {0, 0, 0};
   bool jobs_pairk = false;
-  bool jobs_pair_dual = false;
+  int jobs_pair_mode = 0;               // 0: one job per tap, 1: staged both-taps job, 2: transposed-read both-taps job
   // the head layers' weight gradients as staged pair jobs (kinds 1..4) on the head's own time split
   int hpair_first[6] = {0, 0, 0, 0, 0, 0}, hpair_count[6] = {0, 0, 0, 0, 0, 0};
   bool jobs_headpairs = false;
@@ -1645,16 +1645,18 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool pairk = !layerk && p->LPB == 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
                      wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
                      wn_debug_get(13) != 1;
-  // knob 16 = 2: both taps of a block's gated conv as ONE job (du read once).  Measured slower at configs[3] (22.1 vs
-  // 16.4 ms per step): 128 accumulator registers per wave beside the staging registers spill (80 VGPRs)
-  const bool pair_dual = pairk && wn_debug_get(16) == 2;
+  // Both taps of a block's gated conv as ONE job (du read once): by the transposed-LDS-read kernel (wn_wgrad_tr.hip,
+  // default); knob 16 = 1: one staged job per tap (du read twice); = 2: the staged kernel with both taps (128 accumulator
+  // registers beside its staging registers: spills, 22.1 vs 16.4 ms per step at configs[3])
+  const int pair_mode = !pairk ? 0 : (wn_debug_get(16) == 1 ? 0 : (wn_debug_get(16) == 2 ? 1 : 2));
+  const bool pair_dual = pair_mode != 0;
   const bool fold = fold_ok(p);
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
   // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
   const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_pair_dual == pair_dual && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
+      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
   std::vector<WnWgLayer> wgl;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
@@ -1794,7 +1796,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_dual = pair_dual; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
   p->jobs_fold = fold;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
@@ -2137,6 +2139,12 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       if (p->jobs_headpairs)
         for (int kd = 1; kd <= 5; ++kd)
           if (p->hpair_count[kd] > 0) {
+            // staged kinds 1 (128 x 256), 3 (256 x 128), 5 (256 x 256 halves) have transposed-read forms (3, 4, 5); knob 16 = 1: staged
+            const int trk = kd == 1 ? 3 : (kd == 3 ? 4 : (kd == 5 ? 5 : (kd == 2 ? 2 : 0)));
+            if (trk != 0 && p->jobs_pair_mode == 2)        // (with 64-channel blocks the staged head jobs are faster beside the side stream's neighbours)
+              rc = wn_launch_wgrad_tr(trk, p->d_pairs + p->hpair_first[kd], p->hpair_count[kd], ws, ws + L.hslab - L.head_base,
+                                      L.head_span, B, T, L.hsplits, fork ? p->side : s);
+            else
             rc = wn_launch_wgrad_pairs(kd, p->d_pairs + p->hpair_first[kd], p->hpair_count[kd], ws, ws + L.hslab - L.head_base,
                                        L.head_span, B, T, L.hsplits, fork ? p->side : s);
             if (rc) return rc;
@@ -2145,8 +2153,12 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
     for (int kd = 1; kd <= 2; ++kd)
       if (p->jobs_pairk && p->pair_count[kd] > 0) {
-        rc = wn_launch_wgrad_pairs(kd == 1 && p->jobs_pair_dual ? 6 : kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws,
-                                   ws + L.bslab, p->nparams, B, T, L.bsplits, s);
+        if (p->jobs_pair_mode == 2)                     // transposed-read kernels: both taps of dW_d in one job; dW_r
+          rc = wn_launch_wgrad_tr(kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws, ws + L.bslab, p->nparams, B, T,
+                                  L.bsplits, s);
+        else
+          rc = wn_launch_wgrad_pairs(kd == 1 && p->jobs_pair_mode == 1 ? 6 : kd, p->d_pairs + p->pair_first[kd],
+                                     p->pair_count[kd], ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
         if (rc) return rc;
       }
     if (p->jobs_layerk) {
