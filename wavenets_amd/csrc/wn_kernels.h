@@ -105,6 +105,9 @@ struct WnWgPair {
   int64_t w_off, b_off;            // dW[k][n] -> slab row + w_off + k * N + n; db -> slab row + b_off (or < 0)
   int64_t gmax_off;                // running max-abs of G, or < 0
   int32_t shift, pad_;             // X row = t - shift
+  // transposed-read kernel, two-source form (kind 6): the upper half of G's columns comes from a second tensor and its
+  // product goes to a second slab -- dW_r = z^T g_o and M = z^T dL/da (folded skip path) from ONE read of z
+  int64_t g2_off, w2_off, b2_off, gmax2_off;
 };
 int wn_wgrad_pair_kind(int K, int N);
 int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
@@ -113,7 +116,7 @@ int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws
 // (wn_wgrad_tr.hip); jobs: x_off, g_off, shift = dilation, w_off = tap 0's offset, b_off, gmax_off
 int wn_wgrad_tr_kind(int K, int N, int taps);
 int wn_launch_wgrad_tr(int kind, const WnWgPair* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
-                       int splits_per_b, hipStream_t s);
+                       int splits_per_b, hipStream_t s, float* slab2 = nullptr, int64_t P2 = 0);
 // two products of the backward-data chain per launch: g_x(b+1) and, from it in registers, g_u(b) (wn_bwd_pair.hip)
 struct WnBwdPairArgs {
   const float* gu_in;    // g_u(b+1) [rows][2D]

@@ -100,6 +100,7 @@ struct wn_plan {
   WnWgPair* d_pairs = nullptr;
   int pair_first[3] = {0, 0, 0}, pair_count[3] = {0, 0, 0};
   bool jobs_pairk = false;
+  bool jobs_mfused = false;             // M = Z^T dL/da of the folded skip path rides in the dW_r jobs
   int jobs_pair_mode = 0;               // 0: one job per tap, 1: staged both-taps job, 2: transposed-read both-taps job
   // the head layers' weight gradients as staged pair jobs (kinds 1..4) on the head's own time split
   int hpair_first[6] = {0, 0, 0, 0, 0, 0}, hpair_count[6] = {0, 0, 0, 0, 0, 0};
@@ -1650,13 +1651,16 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   // registers beside its staging registers: spills, 22.1 vs 16.4 ms per step at configs[3])
   const int pair_mode = !pairk ? 0 : (wn_debug_get(16) == 1 ? 0 : (wn_debug_get(16) == 2 ? 1 : 2));
   const bool pair_dual = pair_mode != 0;
+  // with the transposed-read kernels the folded skip path's M = Z^T dL/da is computed by the dW_r jobs (knob 16 = 3: own kernel)
+  const bool mfused = pair_mode == 2 && fold_ok(p) && p->fold_F0 == 128 && p->D == 128 && p->Dp == p->D && p->S > 0 &&
+                      wn_debug_get(16) != 3;
   const bool fold = fold_ok(p);
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
   // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
   const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
+      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_mfused == mfused && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
   std::vector<WnWgLayer> wgl;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
@@ -1715,6 +1719,13 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       w.x_off = zoff; w.g_off = p->S == 0 ? L.GO[b] : L.GH[b + 1]; w.shift = 0;
       w.w_off = p->tensors[bi.conv1.kernel_t].off; w.b_off = p->tensors[bi.conv1.bias_t].off;
       w.gmax_off = p->S == 0 ? am_skip : am_GH(b + 1);
+      w.g2_off = w.w2_off = w.b2_off = w.gmax2_off = -1;
+      if (mfused) {
+        // the folded skip path's M(b) = z_b^T dL/da rides in the same job (one read of z_b): second slab = mslab
+        w.g2_off = L.GF[0]; w.w2_off = (int64_t)b * p->D * p->fold_F0;
+        w.b2_off = b == 0 ? (int64_t)p->N * p->D * p->fold_F0 : -1;       // colsum(dL/da) once
+        w.gmax2_off = L.absmax + 0;                                        // am_GF(0)
+      }
       pairs[2].push_back(w);
     } else {
     // the dilated stack: conv i reads H[b] (or its dropped copy) / the activated output of conv i - 1; its output gradient
@@ -1796,7 +1807,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_mfused = mfused; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
   p->jobs_fold = fold;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
@@ -2153,9 +2164,10 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
     for (int kd = 1; kd <= 2; ++kd)
       if (p->jobs_pairk && p->pair_count[kd] > 0) {
-        if (p->jobs_pair_mode == 2)                     // transposed-read kernels: both taps of dW_d in one job; dW_r
-          rc = wn_launch_wgrad_tr(kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws, ws + L.bslab, p->nparams, B, T,
-                                  L.bsplits, s);
+        if (p->jobs_pair_mode == 2)                     // transposed-read kernels: both taps of dW_d in one job; dW_r (+ M)
+          rc = wn_launch_wgrad_tr(kd == 2 && p->jobs_mfused ? 6 : kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws,
+                                  ws + L.bslab, p->nparams, B, T, L.bsplits, s, ws + L.mslab,
+                                  (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0);
         else
           rc = wn_launch_wgrad_pairs(kd == 1 && p->jobs_pair_mode == 1 ? 6 : kd, p->d_pairs + p->pair_first[kd],
                                      p->pair_count[kd], ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
@@ -2169,9 +2181,11 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       // M = Z^T dL/da (N*D x F0) and colsum(dL/da) into their own slab, reduced, then the three small products
       const int F0 = p->fold_F0;
       const int64_t pm = (int64_t)p->N * p->D * F0 + F0;
+      if (!p->jobs_mfused) {
       rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.GF[0], F0, rows, p->N * p->D, F0, p->D, B * L.bsplits, ws + L.mslab, pm,
                                 0, (int64_t)p->D * F0, (int64_t)p->N * p->D * F0, 0, 1, am_GF(0), s);
       if (rc) return rc;
+      }
       rc = wn_launch_reduce_table(ws + L.mslab, B * L.bsplits, pm, ws + L.mtot, p->d_cov_fold, 1, s);
       if (rc) return rc;
       const BlockInfo& b0 = p->blocks[0];

@@ -55,9 +55,11 @@ __device__ __forceinline__ void wt_split4(const f32x4& v, float s, wt_h4& hi, wt
 // KC = channels of X (per tap), NC = channels of G, TAPS = 2: X is x[t - shift] | x[t] (both taps of a kernel-size-2
 // conv, stacked along the output's k index); TAPS = 1: one product with row shift `shift`.  LDX / LDG / LDW: row strides of
 // X, G and of the dW matrix (G and dW may be a column half of a wider tensor).  TKW x TNW = output tiles per wave.
-template <int KC, int NC, int TAPS, int LDX, int LDG, int LDW, int TKW, int TNW>
+// G2: G is two tensors of NC / 2 channels each (J.g_off | J.g2_off, row stride LDG both); the lower half's product goes to
+// (slab, w_off, b_off) as usual, the upper half's to (slab2, w2_off, b2_off), both with row pitch LDW.
+template <int KC, int NC, int TAPS, int LDX, int LDG, int LDW, int TKW, int TNW, bool G2 = false>
 __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* jobs, float* ws, float* slab, int64_t P, int B,
-                                                             int T, int spb) {
+                                                             int T, int spb, float* slab2, int64_t P2) {
   constexpr int XC = TAPS * KC, NCH = XC + NC;                  // LDS channels: x taps | g
   constexpr int PITCH = NCH * 2 + 64;                           // bytes per time row of a plane (the pad spreads 4 rows over the banks)
   constexpr int PLANE = WT_ROWS * PITCH, STAGE = 2 * PLANE;
@@ -79,23 +81,30 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
   const int r0 = sp * len, r1 = min(T, r0 + len);
   const int d = J.shift;
 
-  float gsc = 1.0f, inv = 1.0f;
-  if (J.gmax_off >= 0) {
-    const float m = ws[J.gmax_off];
-    if (m > 0.f && m < 3.0e38f) {
-      int e;
-      (void)frexpf(m, &e);
-      e = max(-100, min(100, e));
-      gsc = ldexpf(1.0f, -e);
-      inv = ldexpf(1.0f, e);
+  auto pow2 = [&](int64_t off, float& sc, float& iv) {
+    sc = 1.0f; iv = 1.0f;
+    if (off >= 0) {
+      const float m = ws[off];
+      if (m > 0.f && m < 3.0e38f) {
+        int e;
+        (void)frexpf(m, &e);
+        e = max(-100, min(100, e));
+        sc = ldexpf(1.0f, -e);
+        iv = ldexpf(1.0f, e);
+      }
     }
-  }
+  };
+  float gsc, inv, gsc2 = 1.0f, inv2 = 1.0f;
+  pow2(J.gmax_off, gsc, inv);
+  if constexpr (G2) pow2(J.gmax2_off, gsc2, inv2);
 
   // ---- this thread's pieces of a chunk: rows xr + XRP k of every x tap (4 channels at xc), rows gr + GRP k of g (4 at gc) ----
   const int xr = tid / XPR, xc = (tid % XPR) * 4;
   const int gr = tid / GPR, gc = (tid % GPR) * 4;
   const float* xbase = ws + J.x_off + (int64_t)ub * T * LDX + xc;
-  const float* gbase = ws + J.g_off + (int64_t)ub * T * LDG + gc;
+  const bool upper = G2 && gc >= NC / 2;                 // this thread's g piece belongs to the second tensor
+  const float* gbase = upper ? ws + J.g2_off + (int64_t)ub * T * LDG + (gc - NC / 2) : ws + J.g_off + (int64_t)ub * T * LDG + gc;
+  const float gs_t = upper ? gsc2 : gsc;
   f32x4 xs[TAPS][XP], gv[GP];                            // the chunk in flight: x[t - shift] (| x[t]), g
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
     for (int k = 0; k < GP; ++k) {
       wt_h4 hi, lo;
       unsigned char* row = st + (gr + GRP * k) * PITCH;
-      wt_split4(gv[k], gsc, hi, lo);
+      wt_split4(gv[k], gs_t, hi, lo);
       bsum[0] += gv[k].x; bsum[1] += gv[k].y; bsum[2] += gv[k].z; bsum[3] += gv[k].w;
       *reinterpret_cast<wt_h4*>(row + (XC + gc) * 2) = hi;
       *reinterpret_cast<wt_h4*>(row + PLANE + (XC + gc) * 2) = lo;
@@ -197,15 +206,20 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
 
   // ---- partial results -> this split's slab row (laid out like the flat gradient buffer; taps stacked along k) ----
   float* row = slab + (int64_t)split * P;
+  float* row2 = G2 ? slab2 + (int64_t)split * P2 : nullptr;
 #pragma unroll
   for (int i = 0; i < TKW; ++i) {
-    float* tbase = row + J.w_off + (int64_t)(32 * (kt0 + i)) * LDW + tl;
 #pragma unroll
-    for (int j = 0; j < TNW; ++j)
+    for (int j = 0; j < TNW; ++j) {
+      const int nt = nt0 + j;
+      const bool up = G2 && nt >= NT / 2;                  // wave-uniform
+      float* tbase = (up ? row2 + J.w2_off + 32 * (nt - NT / 2) : row + J.w_off + 32 * nt) + (int64_t)(32 * (kt0 + i)) * LDW + tl;
+      const float iv = up ? inv2 : inv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tbase[wn_drow(r, h) * LDW + 32 * (nt0 + j)] = acc[i][j][r] * inv;
+      for (int r = 0; r < 16; ++r) tbase[wn_drow(r, h) * LDW] = acc[i][j][r] * iv;
+    }
   }
-  if (J.b_off >= 0) {                                    // bias sums: the row groups hold partial sums of every column
+  if (J.b_off >= 0 || (G2 && J.b2_off >= 0)) {           // bias sums: the row groups hold partial sums of every column
     float* bpart = reinterpret_cast<float*>(smem);        // (every wave is past its last LDS read: the loop ends with a barrier)
 #pragma unroll
     for (int e = 0; e < 4; ++e) bpart[gr * NC + gc + e] = bsum[e];
@@ -214,13 +228,12 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
       float s8 = 0.f;
 #pragma unroll
       for (int g = 0; g < GRP; ++g) s8 += bpart[g * NC + n];
-      row[J.b_off + n] = s8;
+      if (G2 && n >= NC / 2) { if (J.b2_off >= 0) row2[J.b2_off + n - NC / 2] = s8; }
+      else if (J.b_off >= 0) row[J.b_off + n] = s8;
     }
   }
 }
 
-// kind 1: both taps of a 128 -> 256 kernel-size-2 conv (dW_d of a 128-channel block); 2: 128 x 128 (dW_r); 3: 128 x 256
-// (a 128 -> 256 head layer); 4: 256 x 128; 5: 256 x 256 as two 128-column halves (G and dW keep their pitch of 256)
 int wn_wgrad_tr_kind(int K, int N, int taps) {
   if (taps == 2) return (K == 128 && N == 256) ? 1 : 0;
   if (K == 128 && N == 128) return 2;
@@ -231,16 +244,21 @@ int wn_wgrad_tr_kind(int K, int N, int taps) {
 }
 
 int wn_launch_wgrad_tr(int kind, const WnWgPair* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
-                       int splits_per_b, hipStream_t s) {
+                       int splits_per_b, hipStream_t s, float* slab2, int64_t P2) {
   if (njobs <= 0) return WN_OK;
   const dim3 grid((unsigned)(B * splits_per_b), (unsigned)njobs);
-#define WT_LAUNCH(...) hipLaunchKernelGGL((wn_wgrad_tr_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b)
+#define WT_LAUNCH(...) hipLaunchKernelGGL((wn_wgrad_tr_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b, slab2, P2)
   switch (kind) {
     case 1: WT_LAUNCH(128, 256, 2, 128, 256, 256, 2, 4); break;
     case 2: WT_LAUNCH(128, 128, 1, 128, 128, 128, 1, 2); break;
     case 3: WT_LAUNCH(128, 256, 1, 128, 256, 256, 1, 4); break;
     case 4: WT_LAUNCH(256, 128, 1, 256, 128, 128, 2, 2); break;
     case 5: WT_LAUNCH(256, 128, 1, 256, 256, 256, 2, 2); break;
+    // dW_r = z^T g_o and M = z^T dL/da of a 128-channel block from one read of z (two 128-column products, pitch 128)
+    case 6:
+      if (!slab2) { wn_set_error("wgrad_tr: kind 6 needs the second slab"); return WN_E_INVALID; }
+      WT_LAUNCH(128, 256, 1, 128, 128, 128, 1, 4, true);
+      break;
     default: wn_set_error("wgrad_tr: unknown kind %d", kind); return WN_E_UNSUPPORTED;
   }
 #undef WT_LAUNCH
