@@ -134,6 +134,9 @@ struct WnBwdPairArgs {
 };
 int wn_bwd_pair_supported(int R, int D, int KS, int F0);
 int wn_launch_bwd_pair(const WnBwdPairArgs& a, hipStream_t s);
+// the same two products for 128-channel blocks, weight images streamed through an LDS ring (wn_bwd16s.hip)
+int wn_bwd_s128_supported(int R, int D, int KS, int F0);
+int wn_launch_bwd_s128(const WnBwdPairArgs& a, hipStream_t s);
 // dW_s / db_s of the folded skip path for all blocks (wn_wgrad_skip.hip)
 int wn_wgrad_skip_supported(int D, int S, int KZ);
 int wn_launch_wgrad_skip(const float* z, int ldz, const float* g, int ldg, int64_t rows, int KZ, int S, int D,

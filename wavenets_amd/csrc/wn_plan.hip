@@ -1278,6 +1278,8 @@ extern "C" int wn_plan_describe(const wn_plan* p, char* buf, int32_t len) {
   else if (p->LPB > 1) bwd = "per-block composed backward, one rows contraction per conv of the stack (layers_per_block > 1)";
   else if (fold && p->N >= 2 && wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1)
     bwd = "two products per launch (wn_bwd_pair_kernel: g_x(b+1) and g_u(b))";
+  else if (fold && p->N >= 2 && wn_bwd_s128_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1)
+    bwd = "two products per launch, weights streamed through an LDS ring (wn_bwd_s128_kernel: g_x(b+1) and g_u(b))";
   else if (!exact) bwd = "two split-precision rows contractions per block (g_u with the gate derivative, g_x)";
   else bwd = "two exact-fp32 rows contractions per block";
   const char* wg;
@@ -2034,7 +2036,8 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     // Two products per launch (wn_bwd_pair.hip): g_x(b+1) and, from it in registers, g_u(b).  The chain is then
     //   g_u(N-1) | { g_x(b+1), g_u(b) } for b = N-2 .. 0 | g_x(0)   = N + 1 launches instead of 2 N.   knob 22 = 1: two launches per block
     const bool pairk = fold && p->N >= 2 && p->drop_rate == 0.f && p->c.use_residual && (p->c.cond_inputs == 0 || cond_batched) && !have_gzs &&
-                       wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1 &&
+                       (wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) || wn_bwd_s128_supported(p->R, p->D, p->KS, p->fold_F0)) &&
+                       p->Dp == p->D && wn_debug_get(22) != 1 &&
                        wn_debug_get(15) != 1;
     for (int b = p->N - 1; b >= 0; --b) {
       BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
@@ -2050,7 +2053,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         a.am_gu_in = am_GU(b + 1); a.am_gf = am_GF(0); a.am_gx = am_GH(b + 1); a.am_gu = am_GU(b);
         a.B = B; a.T = T; a.dil = k1.dil[0];
         if (!a.wx16 || !a.wu16) { wn_set_error("bwd_pair: weight images missing"); return WN_E_UNSUPPORTED; }
-        rc = wn_launch_bwd_pair(a, s);
+        rc = p->R == 128 ? wn_launch_bwd_s128(a, s) : wn_launch_bwd_pair(a, s);
         if (rc) return rc;
         if (b == 0) {
           // g_x(0): the gradient at the first block's input (only the input conv's weight gradients need it)
