@@ -104,6 +104,8 @@ __device__ __forceinline__ void store_tile(const f32x16& v, float* stage, float*
   asm volatile("" ::: "memory");
 }
 
+}  // namespace
+
 // RESMODE 0: no residual; 1: x_out = o + (a.res ? a.res : a.x).  SAVE: the sigmoid is written for backward (training).
 //
 // Two workgroups of FOUR waves per CU (75 KiB of LDS, <= 256 registers per lane each): a wave that stores and then waits
@@ -408,8 +410,6 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_s128_kernel(WnLayerFwdArg
     if (lane == 0) wn_absmax_publish_any(a.absmax_out, wmax);
   }
 }
-
-}  // namespace
 
 int wn_layer_fwd_s128_supported(int R, int D, int KS) { return R == 128 && D == 128 && KS == 2; }
 
