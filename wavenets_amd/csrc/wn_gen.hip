@@ -750,12 +750,13 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
           gn_mac<KS2>(o, wc[s], reinterpret_cast<const gn_h8*>(zop + (b & 1) * ZOP_BYTES) + lane);
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = a.residual ? o[r] + x[r] : o[r];
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) xm = wn_absmax_acc(xm, x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]);
           if (b + 1 < nblocks) put_xop(x, cw);
           if (cw == 0) GN_TS(1, b, 4);
           GN_BARRIER();                               // (3) x operands visible
           if (cw == 0) GN_TS(1, b, 5);
+          // (range guard bookkeeping behind the hand-over: the conv1 waves idle through the next block's phases A and B)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) xm = wn_absmax_acc(xm, x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]);
           {                                           // refill of set s, issued while the conv1 waves idle (phases A, B)
             fetch_c(sc, b + NS < nblocks, tbl[min(b + NS, nblocks - 1)].w16r_off);
           }
