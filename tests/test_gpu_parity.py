@@ -242,6 +242,11 @@ MODEL_CASES = {
     'cat_noskipch': dict(blocks=5, channels=32, dilation_bound=16, final_layers_channels=[], bits=8),
     'cat_r64': dict(blocks=4, channels=64, skip_channels=256, dilation_bound=1024, final_layers_channels=[128, 256],
                     activation='leaky_relu', bits=8),
+    # 32-channel blocks under a 128-wide first head conv: the folded skip path's M = Z^T dL/da as ONE transposed-read job
+    # over five of its eight z segments (wn_wgrad_tr kind 8; 'cat_r64' fills a kind-7 job, the 30-block nets end on a
+    # two-segment job)
+    'cat_r32_f128': dict(blocks=5, channels=32, skip_channels=96, dilation_bound=16, final_layers_channels=[128, 48],
+                         activation='leaky_relu', bits=8),
     'cat_r128': dict(blocks=3, channels=128, skip_channels=64, dilation_bound=8, final_layers_channels=[64],
                      activation='leaky_relu', bits=8),
     'cat_odd_composed': dict(blocks=4, channels=12, dilation_channels=10, skip_channels=20, dilation_bound=4,

@@ -101,6 +101,7 @@ struct wn_plan {
   int pair_first[3] = {0, 0, 0}, pair_count[3] = {0, 0, 0};
   bool jobs_pairk = false;
   bool jobs_mfused = false;             // M = Z^T dL/da of the folded skip path rides in the dW_r jobs
+  int jobs_mtr = 0;                     // ... or is its own transposed-read launch over several blocks' z (kind 7 / 8; pairs index 0)
   int jobs_pair_mode = 0;               // 0: one job per tap, 1: staged both-taps job, 2: transposed-read both-taps job
   // the head layers' weight gradients as staged pair jobs (kinds 1..4) on the head's own time split
   int hpair_first[6] = {0, 0, 0, 0, 0, 0}, hpair_count[6] = {0, 0, 0, 0, 0, 0};
@@ -1289,7 +1290,12 @@ extern "C" int wn_plan_describe(const wn_plan* p, char* buf, int32_t len) {
     wg = "one workgroup per (block, utterance, time range) for dW_d, db_d, dW_r, db_r (wn_wgrad_layer_kernel)";
   else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(13) != 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D &&
            wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 && wn_wgrad_pair_kind(p->D, p->R) == 2)
-    wg = "staged pair jobs, three per block (wn_wgrad_pair_kernel)";
+    wg = wn_debug_get(16) == 1 || wn_debug_get(16) == 2
+             ? "staged pair jobs (wn_wgrad_pair_kernel)"
+             : (wn_debug_get(16) == 0 && fold && p->fold_F0 == 128 && p->D == 128
+                    ? "two jobs per block on transposed LDS reads: both taps of dW_d from one read of du; dW_r together with the "
+                      "folded skip path's M = Z^T dL/da from one read of z (wn_wgrad_tr_kernel)"
+                    : "two jobs per block on transposed LDS reads: both taps of dW_d from one read of du; dW_r (wn_wgrad_tr_kernel)");
   else wg = "generic batched job table (wn_wgrad_batched_kernel)";
   snprintf(buf, (size_t)len,
            "math: %s | block forward: %s | skip path: %s | backward data: %s | block weight gradients: %s",
@@ -1654,15 +1660,20 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const int pair_mode = !pairk ? 0 : (wn_debug_get(16) == 1 ? 0 : (wn_debug_get(16) == 2 ? 1 : 2));
   const bool pair_dual = pair_mode != 0;
   // with the transposed-read kernels the folded skip path's M = Z^T dL/da is computed by the dW_r jobs (knob 16 = 3: own kernel)
-  const bool mfused = pair_mode == 2 && fold_ok(p) && p->fold_F0 == 128 && p->D == 128 && p->Dp == p->D && p->S > 0 &&
+  // ... and by the per-block kernel of 32 / 64-channel blocks, which stages z anyway (wn_wgrad_layer_kernel<.., true>)
+  const bool mfused = pair_mode == 2 && p->D == 128 && fold_ok(p) && p->fold_F0 == 128 && p->Dp == p->D && p->S > 0 &&
                       wn_debug_get(16) != 3;
+  // 64- / 32-channel blocks: M as transposed-read jobs over the z of four / eight blocks at a time against one read of
+  // dL/da (wn_wgrad_tr kinds 7 / 8; knob 16 = 3: wn_wgrad_skip_kernel)
+  const int mtr = (layerk && fold_ok(p) && p->fold_F0 == 128 && p->Dp == p->D && p->S > 0 && wn_debug_get(16) != 3)
+                      ? (p->D == 64 ? 7 : (p->D == 32 ? 8 : 0)) : 0;
   const bool fold = fold_ok(p);
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
   // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
   const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_mfused == mfused && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
+      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_mfused == mfused && p->jobs_mtr == mtr && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
   std::vector<WnWgLayer> wgl;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
@@ -1757,6 +1768,22 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       cover(bi.conv_skip.kernel_t); cover(bi.conv_skip.bias_t);
     }
   }
+  if (mtr != 0) {
+    const int per = 256 / p->D;                               // blocks per job
+    for (int b0 = 0; b0 < p->N; b0 += per) {
+      WnWgPair w;
+      memset(&w, 0, sizeof(w));
+      w.x_off = L.Z + (int64_t)b0 * B * T * p->Dp;            // block-major Z: segment stride = one block's plane
+      w.g2_off = (int64_t)B * T * p->Dp;
+      w.pad_ = std::min(per, p->N - b0);
+      w.g_off = L.GF[0]; w.shift = 0;
+      w.w_off = (int64_t)b0 * p->D * p->fold_F0;
+      w.b_off = b0 == 0 ? (int64_t)p->N * p->D * p->fold_F0 : -1;       // colsum(dL/da) once
+      w.gmax_off = L.absmax + 0;                              // am_GF(0)
+      w.w2_off = w.b2_off = w.gmax2_off = -1;
+      pairs[0].push_back(w);
+    }
+  }
   p->head_first = (int)jobs.size();
   p->cov_head_first = (int)cov.size();
   for (size_t i = fold ? 1 : 0; i < p->finals.size(); ++i) {      // (folded: the first conv's gradients come from M too)
@@ -1794,7 +1821,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   if (p->d_pairs) { (void)hipFree(p->d_pairs); p->d_pairs = nullptr; }
   {
     std::vector<WnWgPair> all;
-    for (int kd = 1; kd <= 2; ++kd) {
+    for (int kd = 0; kd <= 2; ++kd) {
       p->pair_first[kd] = (int)all.size();
       p->pair_count[kd] = (int)pairs[kd].size();
       all.insert(all.end(), pairs[kd].begin(), pairs[kd].end());
@@ -1809,7 +1836,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_mfused = mfused; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_mfused = mfused; p->jobs_mtr = mtr; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
   p->jobs_fold = fold;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
@@ -2184,11 +2211,13 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       // M = Z^T dL/da (N*D x F0) and colsum(dL/da) into their own slab, reduced, then the three small products
       const int F0 = p->fold_F0;
       const int64_t pm = (int64_t)p->N * p->D * F0 + F0;
-      if (!p->jobs_mfused) {
+      if (p->jobs_mtr != 0)
+        rc = wn_launch_wgrad_tr(p->jobs_mtr, p->d_pairs + p->pair_first[0], p->pair_count[0], ws, ws + L.mslab, pm, B, T,
+                                L.bsplits, s);
+      else if (!p->jobs_mfused)
       rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.GF[0], F0, rows, p->N * p->D, F0, p->D, B * L.bsplits, ws + L.mslab, pm,
                                 0, (int64_t)p->D * F0, (int64_t)p->N * p->D * F0, 0, 1, am_GF(0), s);
       if (rc) return rc;
-      }
       rc = wn_launch_reduce_table(ws + L.mslab, B * L.bsplits, pm, ws + L.mtot, p->d_cov_fold, 1, s);
       if (rc) return rc;
       const BlockInfo& b0 = p->blocks[0];

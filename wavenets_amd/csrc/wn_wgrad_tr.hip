@@ -57,7 +57,11 @@ __device__ __forceinline__ void wt_split4(const f32x4& v, float s, wt_h4& hi, wt
 // X, G and of the dW matrix (G and dW may be a column half of a wider tensor).  TKW x TNW = output tiles per wave.
 // G2: G is two tensors of NC / 2 channels each (J.g_off | J.g2_off, row stride LDG both); the lower half's product goes to
 // (slab, w_off, b_off) as usual, the upper half's to (slab2, w2_off, b2_off), both with row pitch LDW.
-template <int KC, int NC, int TAPS, int LDX, int LDG, int LDW, int TKW, int TNW, bool G2 = false>
+// XSEG > 0 (TAPS = 1, not G2): the KC channels of X are KC / XSEG tensors of XSEG channels each (row stride LDX = XSEG),
+// J.g2_off floats apart, of which the first J.pad_ exist (the rest reads as zero and its output rows are not written):
+// the gated activations z of several blocks (block-major Z) against ONE read of G -- the folded skip path's
+// M = Z^T dL/da (src/layers.py:216-217 and model.py:105-111 reversed) for 64- and 32-channel blocks.
+template <int KC, int NC, int TAPS, int LDX, int LDG, int LDW, int TKW, int TNW, bool G2 = false, int XSEG = 0>
 __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* jobs, float* ws, float* slab, int64_t P, int B,
                                                              int T, int spb, float* slab2, int64_t P2) {
   constexpr int XC = TAPS * KC, NCH = XC + NC;                  // LDS channels: x taps | g
@@ -66,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
   constexpr int KT = XC / 32, NT = NC / 32;
   static_assert((KT / TKW) * (NT / TNW) == 8 && KT % TKW == 0 && NT % TNW == 0, "8 waves tile the output block");
   static_assert((PITCH / 4) % 64 == 16, "row pitch must rotate the banks by a quarter");
+  static_assert(XSEG == 0 || (TAPS == 1 && !G2 && LDX == XSEG && KC % XSEG == 0 && XSEG % 32 == 0), "segmented X");
   constexpr int XPR = KC / 4, GPR = NC / 4;                     // 16-byte pieces per row
   constexpr int XRP = 512 / XPR, GRP = 512 / GPR;               // rows per pass of the 512 threads
   constexpr int XP = WT_ROWS / XRP, GP = WT_ROWS / GRP;         // passes per chunk
@@ -101,7 +106,10 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
   // ---- this thread's pieces of a chunk: rows xr + XRP k of every x tap (4 channels at xc), rows gr + GRP k of g (4 at gc) ----
   const int xr = tid / XPR, xc = (tid % XPR) * 4;
   const int gr = tid / GPR, gc = (tid % GPR) * 4;
-  const float* xbase = ws + J.x_off + (int64_t)ub * T * LDX + xc;
+  const int nseg = XSEG > 0 ? J.pad_ : 0;
+  const bool xvalid = XSEG == 0 || xc / (XSEG > 0 ? XSEG : 1) < nseg;
+  const float* xbase = XSEG > 0 ? ws + J.x_off + (int64_t)(xvalid ? xc / (XSEG > 0 ? XSEG : 1) : 0) * J.g2_off + (int64_t)ub * T * LDX + xc % (XSEG > 0 ? XSEG : 1)
+                                : ws + J.x_off + (int64_t)ub * T * LDX + xc;
   const bool upper = G2 && gc >= NC / 2;                 // this thread's g piece belongs to the second tensor
   const float* gbase = upper ? ws + J.g2_off + (int64_t)ub * T * LDG + (gc - NC / 2) : ws + J.g_off + (int64_t)ub * T * LDG + gc;
   const float gs_t = upper ? gsc2 : gsc;
@@ -114,7 +122,9 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
       const int t = t0 + xr + XRP * k;
-      if (interior) {
+      if (XSEG > 0) {
+        xs[0][k] = (xvalid && (interior || t < r1)) ? wt_ldg4(xbase + (int64_t)t * LDX) : zero4;
+      } else if (interior) {
         xs[0][k] = wt_ldg4(xbase + (int64_t)(t - d) * LDX);
         if constexpr (TAPS == 2) xs[1][k] = wt_ldg4(xbase + (int64_t)t * LDX);
       } else {
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
   float* row2 = G2 ? slab2 + (int64_t)split * P2 : nullptr;
 #pragma unroll
   for (int i = 0; i < TKW; ++i) {
+    if (XSEG > 0 && 32 * (kt0 + i) >= nseg * XSEG) continue;      // rows of a segment that does not exist (wave-uniform)
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
       const int nt = nt0 + j;
@@ -259,6 +270,9 @@ int wn_launch_wgrad_tr(int kind, const WnWgPair* d_jobs, int njobs, float* ws, f
       if (!slab2) { wn_set_error("wgrad_tr: kind 6 needs the second slab"); return WN_E_INVALID; }
       WT_LAUNCH(128, 256, 1, 128, 128, 128, 1, 4, true);
       break;
+    // M = Z^T dL/da: the z of four 64-channel (kind 7) or eight 32-channel blocks (kind 8) against one read of dL/da
+    case 7: WT_LAUNCH(256, 128, 1, 64, 128, 128, 2, 2, false, 64); break;
+    case 8: WT_LAUNCH(256, 128, 1, 32, 128, 128, 2, 2, false, 32); break;
     default: wn_set_error("wgrad_tr: unknown kind %d", kind); return WN_E_UNSUPPORTED;
   }
 #undef WT_LAUNCH
