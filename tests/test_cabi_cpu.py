@@ -159,7 +159,7 @@ def test_plan_describe_names_the_kernel_family_of_every_phase():
   c1 = describe(_cfg(channels=64, **base))                                   # BASELINE configs[1]
   assert 'wn_layer_fwd_f16_kernel' in c1 and 'wn_bwd_pair_kernel' in c1 and 'wn_wgrad_layer_kernel' in c1 and 'folded' in c1
   c3 = describe(_cfg(channels=128, num_mixtures=10, sampling_function='logistic', bits=16, **base))     # configs[3]
-  assert 'wn_layer_fwd_s128_kernel' in c3 and 'wn_wgrad_pair_kernel' in c3 and 'folded' in c3
+  assert 'wn_layer_fwd_s128_kernel' in c3 and 'wn_bwd_s128_kernel' in c3 and 'wn_wgrad_tr_kernel' in c3 and 'folded' in c3
   d = describe(_cfg(blocks=5, layers_per_block=5, dilation_bound=256, num_mixtures=8, sampling_function='gaussian', bits=16,
                     final_layers_channels=[128, 256], activation='leaky_relu'))   # the reference's default (train.py:22-50)
   assert 'layers_per_block > 1' in d

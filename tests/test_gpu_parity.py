@@ -960,6 +960,27 @@ def test_queued_generation_launch_variants_agree(name, det):
     assert torch.equal(naive, queued), (key, val, (naive - queued).abs().max())
 
 
+@pytest.mark.parametrize('name', ['cat_r64', 'cat_r32_f128'])
+@pytest.mark.parametrize('T', [333, 64, 2048 + 17])
+def test_folded_contraction_streamed_forms_agree_bitwise(name, T):
+  """The folded skip contraction's second streamed kernel (wn_gemm16s.hip: four-wave workgroups, two row tiles per wave,
+  weight stream across tiles) runs the old kernel's products in the old order: outputs and logits are bit-identical with
+  knob 31 (old kernel) and knob 30 (one row tile per wave), for ragged tiles too."""
+  from wavenets_amd import _lib
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=21, bias_range=0.3, **kw)
+  x, _ = _inputs(kw, 3, T, seed=5)
+  L = _lib.lib()
+  ref = model.logits(x.to(dev()))
+  for key in (31, 30):
+    try:
+      L.wn_debug_set(key, 1)
+      other = model.logits(x.to(dev()))
+    finally:
+      L.wn_debug_set(key, 0)
+    assert torch.equal(ref, other), (key, (ref - other).abs().max())
+
+
 @pytest.mark.parametrize('skip_channels,finals', [(160, [64]), (256, [128, 256]), (96, [32]), (192, [64, 64])])
 def test_queued_generation_unfolded_skip_contraction(skip_channels, finals):
   """With the fold switched off (knob 21) the chain kernel carries the reference's full-width skip contraction: 3, 5, 6 and

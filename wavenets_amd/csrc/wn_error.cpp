@@ -46,6 +46,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   27  = 1: the categorical sampling tail of a generation step as its own launch (not inside the head launch);
 //       = 2: inside the head launch also for more than 8 utterances
 //   24  = 1: the generation chain kernel stamps its phases with s_memtime for blocks 8..11 (wn_debug_gen_ts reads them)
+//   30  = 1: the streamed planar contraction (wn_gemm16s.hip) with one row tile per wave instead of two
+//   31  = 1: the folded skip contraction on wn_gemm_rows16_kernel (no wn_gemm_planes16s_kernel)
 // thread-local: a caller that switches kernel variants (the range guard's exact-fp32 retry, tools/ A/B runs, tests)
 // affects the launches of its own thread only
 static thread_local int g_wn_debug[32] = {0};

@@ -1,0 +1,229 @@
+// Rows contraction over a PLANAR operand with 128 output columns, streamed weights, second form (gfx950):
+//   Y[t][n] = act( b[n] + sum_p sum_k Z_p[t][k] * W[p * PK + k][n] ),   n < 128, p < NP planes of PK channels each.
+// Its user is the folded skip contraction of a training pass: the skip sum over all blocks' gated activations
+// (src/layers.py:216-217, src/model.py:235-236) folded with the head's first conv (src/model.py:105-111): K = N_blocks * D.
+//
+// Same arithmetic as wn_gemm_rows16_kernel<4, PLAIN> on the same fp16 hi|lo image -- accumulators from zero, k ascending,
+// lo*hi, hi*lo, hi*hi per k-step, then + bias, activation -- so the two kernels agree bit for bit (tested).  What differs is
+// the pipeline, taken from wn_layer16s.hip:
+//   * workgroups of FOUR waves, two per CU, instead of one of eight: one workgroup's barrier waits and tile stores overlap
+//     the other's products;
+//   * the weight stream (8 KiB per k-step: 4 column tiles x hi|lo) runs through a 3-deep LDS ring, two k-steps ahead, and
+//     never stops at a tile boundary (the old kernel drained and refilled its ring per tile);
+//   * a wave owns RT = 2 row tiles (64 time steps): every weight fragment read from LDS feeds two products, and the image
+//     is streamed from L2 once per 256 rows instead of once per 128 (the old kernel's variant of this spilled);
+//   * every request is an inline-assembly LDS-DMA from a scalar base (wn_stream.h), the only waits are counted vmcnt.
+// Measured at configs[1] (K = 1920): 294 -> see DESIGN.md section 9; configs[3] (K = 3840): 0.78 ms -> ibid.
+#include "wn_stream.h"
+
+using namespace wn_stream;
+
+namespace {
+
+template <int RT>
+struct GS {
+  static constexpr int JT = 4;                         // column tiles (128 outputs)
+  static constexpr int CHUNK = JT * 2048, NBUF = 3;    // one k-step of weights
+  static constexpr int XB = 3, XBUF = RT * 2048;       // a wave's activations of one k-step
+  static constexpr int WAVES = 4, THREADS = 256;
+  static constexpr int PITCH = 36, STAGE = 32 * PITCH * 4;
+  static constexpr int REGION = XB * XBUF;             // per wave: activation ring, reused as the output stage
+  static constexpr int LDS = NBUF * CHUNK + WAVES * REGION + 128 * 4;    // + bias table
+  static constexpr int PT = CHUNK / 16 / THREADS;      // weight requests per thread and k-step (2)
+  static constexpr int PX = 2 * RT;                    // activation requests per lane and k-step
+  static_assert(STAGE <= REGION, "the output stage lives in the activation ring");
+};
+
+}  // namespace
+
+// ACT >= 0: the activation fixed at compile time (linear / relu / leaky relu: straight-line epilogue); -1: a.act at run time
+template <int RT, int ACT>
+__global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesArgs a) {
+  using C = GS<RT>;
+  constexpr int JT = C::JT, PT = C::PT, PX = C::PX, PITCH = C::PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = lane & 31, h = lane >> 5;
+  unsigned char* const xbuf = smem + C::NBUF * C::CHUNK + wave * C::REGION;
+  float* stage = reinterpret_cast<float*>(xbuf);
+  const unsigned smem_addr = lds_addr_of(smem), xbuf_addr = lds_addr_of(xbuf);
+  float* sbias = reinterpret_cast<float*>(smem + C::NBUF * C::CHUNK + C::WAVES * C::REGION);
+  if (tid < 128) sbias[tid] = a.bias ? a.bias[tid] : 0.f;
+  const bool has_bias = a.bias != nullptr;
+  __syncthreads();
+
+  const int kpp = a.plane_k >> 4;                      // k-steps per plane
+  const int nsteps = a.nplanes * kpp;                  // >= 3 (launcher)
+  const int tiles_per_b = (a.T + 32 * RT - 1) / (32 * RT);
+  const int64_t ntiles = (int64_t)a.B * tiles_per_b;
+  const int64_t per_pass = (int64_t)gridDim.x * C::WAVES;
+  const int passes = (int)((ntiles + per_pass - 1) / per_pass);
+
+  // the weight stream: k-step ws_next of the image goes to ring slot ws_slot; it wraps at nsteps (next tile)
+  const unsigned woff = (unsigned)tid * 16u;
+  const char* const wimg = reinterpret_cast<const char*>(a.w16);
+  int ws_next = 0, ws_slot = 0;                        // scalar
+  auto wpiece = [&](int i) {
+    dma16(wimg + (int64_t)ws_next * C::CHUNK + 4096 * i, woff, smem_addr + ws_slot * C::CHUNK + (C::THREADS * i + wave * 64) * 16);
+  };
+  auto wadvance = [&]() {
+    ws_next = ws_next + 1 == nsteps ? 0 : ws_next + 1;
+    ws_slot = ws_slot + 1 == C::NBUF ? 0 : ws_slot + 1;
+  };
+#pragma unroll
+  for (int i = 0; i < PT; ++i) wpiece(i);
+  wadvance();
+#pragma unroll
+  for (int i = 0; i < PT; ++i) wpiece(i);
+  wadvance();
+  int slot = 0;                                        // ring slot of the current k-step's weights (scalar)
+  float wmax = 0.f;
+
+  for (int pass = 0; pass < passes; ++pass) {
+    const int64_t tile = ((int64_t)pass * gridDim.x + blockIdx.x) * C::WAVES + wave;
+    const bool live = tile < ntiles;                   // dead waves still take part in the barriers and the weight stream
+    const int b = live ? (int)(tile / tiles_per_b) : 0;
+    const int t0 = live ? (int)(tile % tiles_per_b) * 32 * RT : 0;
+    const int64_t row0 = (int64_t)b * a.T + t0;
+    unsigned xoff[RT];
+    bool xok[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int t = t0 + 32 * rt + tl;
+      xok[rt] = live && t < a.T;
+      xoff[rt] = (unsigned)(((int64_t)b * a.T + (xok[rt] ? t : 0)) * a.ld + 4 * h) * 4u;   // (launcher: a plane stays below 4 GiB)
+    }
+    // the activation stream of this tile: k-step xs_k of plane base xs_base goes to activation buffer xs_buf
+    const char* xs_base = reinterpret_cast<const char*>(a.z);
+    int xs_k = 0, xs_buf = 0;                          // scalar
+    auto xdma = [&]() {
+      const char* base = xs_base + 64 * xs_k;
+      const unsigned dst = xbuf_addr + xs_buf * C::XBUF;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        dma16(base, xoff[rt], dst + rt * 2048);
+        dma16(base + 32, xoff[rt], dst + rt * 2048 + 1024);
+      }
+      if (++xs_k == kpp) { xs_k = 0; xs_base += a.plane_stride * 4; }
+      xs_buf = xs_buf + 1 == C::XB ? 0 : xs_buf + 1;
+    };
+
+    f32x16 acc[RT][JT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][j][r] = 0.f;
+
+    // Issue order per tile:  x0 x1 | step c: wait, barrier, then w(c+2) x(c+2) between the products of k-step c.  (w(0), w(1)
+    // of THIS tile were requested during the previous tile's last two steps, or before the loop.)  vmcnt retires loads in
+    // order: "at most N outstanding" with N = the loads issued after the ones step c needs means those have landed.
+    xdma();
+    xdma();
+    int xcur = 0;                                      // activation buffer of the current step (scalar)
+    // WAIT = loads younger than x(c); XNEXT: x(c + 2) exists
+    auto step = [&](auto wait_, bool xnext) {
+      constexpr int WAIT = decltype(wait_)::value;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const h8* wl = reinterpret_cast<const h8*>(smem + slot * C::CHUNK) + lane;
+      const f32x4* xl = reinterpret_cast<const f32x4*>(xbuf + xcur * C::XBUF) + lane;
+      h8 bh[RT], bl[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 q0 = xl[rt * 128], q1 = xl[rt * 128 + 64];
+        if (!xok[rt]) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+        split8(q0, q1, bh[rt], bl[rt]);
+      }
+      h8 fr[2][2];
+      fr[0][0] = wl[0];
+      fr[0][1] = wl[64];
+      wn_static_for<JT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j + 1 < JT) {
+          fr[(j + 1) & 1][0] = wl[((j + 1) * 2 + 0) * 64];
+          fr[(j + 1) & 1][1] = wl[((j + 1) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc[rt][j] = mfma16(fr[j & 1][1], bh[rt], acc[rt][j]);
+          acc[rt][j] = mfma16(fr[j & 1][0], bl[rt], acc[rt][j]);
+          acc[rt][j] = mfma16(fr[j & 1][0], bh[rt], acc[rt][j]);
+        }
+        // one request group of the look-ahead k-step per product block
+        if constexpr (j < PT) wpiece(j);
+        if constexpr (j == PT) { if (xnext) xdma(); }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      wadvance();
+      slot = slot + 1 == C::NBUF ? 0 : slot + 1;
+      xcur = xcur + 1 == C::XB ? 0 : xcur + 1;
+    };
+    step(std::integral_constant<int, PX>{}, true);                                   // c = 0: younger = x(1)
+    for (int c = 1; c + 1 < nsteps; ++c) step(std::integral_constant<int, PT + PX>{}, c + 2 < nsteps);
+    step(std::integral_constant<int, PT>{}, false);                                  // c = nsteps - 1: younger = w(c + 1)
+
+    // ---- bias, activation, range guard, staged row stores ----
+    const unsigned voff = (unsigned)(lane >> 3) * (unsigned)(a.ldy * 4) + (unsigned)(lane & 7) * 16u;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int rows_valid = live ? max(0, min(32, a.T - (t0 + 32 * rt))) : 0;
+      if (rows_valid <= 0) continue;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int n0 = 32 * j + 8 * rq + 4 * h;
+          float v[4] = {acc[rt][j][4 * rq + 0], acc[rt][j][4 * rq + 1], acc[rt][j][4 * rq + 2], acc[rt][j][4 * rq + 3]};
+          if (has_bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + n0);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], ACT >= 0 ? ACT : a.act);
+          if (xok[rt]) wmax = wn_absmax_acc(wmax, v[0], v[1], v[2], v[3]);
+          acc[rt][j][4 * rq + 0] = v[0]; acc[rt][j][4 * rq + 1] = v[1]; acc[rt][j][4 * rq + 2] = v[2]; acc[rt][j][4 * rq + 3] = v[3];
+        }
+        float* dst = a.y + (row0 + 32 * rt) * a.ldy + 32 * j;
+        if (rows_valid == 32) store_tile<PITCH, true>(acc[rt][j], stage, dst, voff, (unsigned)(a.ldy * 4), rows_valid, lane);
+        else store_tile<PITCH, false>(acc[rt][j], stage, dst, voff, (unsigned)(a.ldy * 4), rows_valid, lane);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead k-steps land before the LDS is given back
+  if (a.absmax_out) {
+    wmax = wn_wave_absmax_bits(wmax);
+    if (lane == 0) wn_absmax_publish_any(a.absmax_out, wmax);
+  }
+}
+
+int wn_gemm_planes16s_supported(int N, int plane_k, int nplanes, int ld, int ldy) {
+  return N == 128 && plane_k >= 16 && plane_k % 16 == 0 && nplanes * (plane_k / 16) >= 3 && ld % 4 == 0 && ld >= plane_k && ldy % 4 == 0 &&
+         ldy >= 128;
+}
+
+int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
+  if (!wn_gemm_planes16s_supported(a.N, a.plane_k, a.nplanes, a.ld, a.ldy)) {
+    wn_set_error("gemm_planes16s: unsupported shape N=%d plane_k=%d planes=%d", a.N, a.plane_k, a.nplanes);
+    return WN_E_UNSUPPORTED;
+  }
+  if ((int64_t)a.B * a.T * a.ld * 4 >= (int64_t)1 << 32) { wn_set_error("gemm_planes16s: plane beyond 4 GiB"); return WN_E_UNSUPPORTED; }
+  if ((int64_t)a.B * a.T <= 0) return WN_OK;
+  const int rt = wn_debug_get(30) == 1 ? 1 : 2;          // knob 30 = 1: one row tile per wave (A/B)
+  const int64_t tiles = (int64_t)a.B * ((a.T + 32 * rt - 1) / (32 * rt));
+  int64_t gx = (tiles + 3) / 4;
+  if (gx > 512) gx = 512;                                // two persistent workgroups of four waves per CU
+#define WN_GS_LAUNCH(RT_, ACT_) hipLaunchKernelGGL((wn_gemm_planes16s_kernel<RT_, ACT_>), dim3((unsigned)gx), dim3(256), 0, s, a)
+  if (rt == 1) WN_GS_LAUNCH(1, -1);
+  else switch (a.act) {
+    case WN_ACT_LINEAR: WN_GS_LAUNCH(2, WN_ACT_LINEAR); break;
+    case WN_ACT_RELU: WN_GS_LAUNCH(2, WN_ACT_RELU); break;
+    case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH(2, WN_ACT_LEAKY_RELU); break;
+    default: WN_GS_LAUNCH(2, -1); break;
+  }
+#undef WN_GS_LAUNCH
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

@@ -71,6 +71,23 @@ int wn_gemm_rows16_ok(const WnGemmArgs& a);
 int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* absmax_in0,
                           const float* absmax_in1, float* absmax_out, hipStream_t s);
 
+// rows contraction over a planar operand with 128 output columns, streamed weights, second form (wn_gemm16s.hip):
+// bit-identical to wn_launch_gemm_rows16 on one planar segment with the PLAIN epilogue
+struct WnGemmPlanesArgs {
+  const float* z;          // plane p, row r: z + p * plane_stride + r * ld
+  int64_t plane_stride;    // floats
+  int32_t ld, plane_k, nplanes;
+  const float* w16;        // fp16 hi|lo image (kind-1 prep, 4 row tiles) of the [nplanes * plane_k][128] weights
+  const float* bias;       // [128] or null
+  int32_t act;
+  float* y; int32_t ldy;
+  int32_t N;               // 128
+  int32_t B, T;
+  float* absmax_out;       // forward range-guard slot or null
+};
+int wn_gemm_planes16s_supported(int N, int plane_k, int nplanes, int ld, int ldy);
+int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- weight-gradient GEMM
 struct WnWgradArgs {
   const float* x; int32_t ldx; int32_t K; int32_t shift;   // dW[k][n] = sum_rows x[t-shift][k] g[t][n]

@@ -1559,6 +1559,15 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   if (fold) {
     // a = act(sum_b V(b)^T z_b + b'): the skip sum and the head's first conv in ONE contraction with F0 output columns
     const ConvInfo& c0 = p->finals[0];
+    // streamed kernel, second form (wn_gemm16s.hip: bit-identical results; knob 31 = 1: wn_gemm_rows16_kernel)
+    if (wn_debug_get(31) != 1 && p->Dp == p->D && wn_gemm_planes16s_supported(c0.cout, p->D, p->N, p->Dp, c0.cout)) {
+      WnGemmPlanesArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.z = ws + L.Z; ga.plane_stride = rows * p->Dp; ga.ld = p->Dp; ga.plane_k = p->D; ga.nplanes = p->N;
+      ga.w16 = fragbase + p->frag16_foldF; ga.bias = ws + L.bfold; ga.act = p->c.activation;
+      ga.y = ws + L.HA[0]; ga.ldy = c0.cout; ga.N = c0.cout; ga.B = B; ga.T = T; ga.absmax_out = fam;
+      rc = wn_launch_gemm_planes16s(ga, s);
+    } else
     rc = Gemm(B, T, c0.cout, ceil32(c0.cout)).seg_planes(ws + L.Z, p->Dp, rows * p->Dp, p->N * p->Dp, nullptr)
              .w16(fragbase + p->frag16_foldF).bias(ws + L.bfold).act(p->c.activation).absmax_fwd(fam)
              .run(ws + L.HA[0], c0.cout, s);
