@@ -34,7 +34,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   16  = 1: 128-channel blocks: one staged weight-gradient job per tap of the gated conv (du read twice) instead of the
 //       transposed-LDS-read kernel with both taps (wn_wgrad_tr.hip); = 2: the staged kernel with both taps (spills, slower)
 //   17  = 1: stacks deeper than 1 (layers_per_block > 1): per-call weight gradients instead of the batched job table
-//   18  = 1: stacks deeper than 1: the batched weight gradients on the split-precision job kernel (inner gradients unscaled: A/B only)
+//   18  = 1: stacks deeper than 1: training passes on the exact-fp32 composed kernels and exact-fp32 batched weight gradients
+//       (no split-precision inner convs with max-abs slots for the inner gradients)
 //   19  = 1: head layers' weight gradients on the generic job table (no staged pair jobs)
 //   20  = 1: input conv's weight gradients on the generic job table (no dedicated reduction kernel)
 //   21  = 1: training passes keep the skip sum and the head's first conv as two steps (no folded V = W_s W_f0 contraction)

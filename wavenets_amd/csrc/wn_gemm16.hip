@@ -835,7 +835,9 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
 
 // eligibility of a rows GEMM for the split-precision kernel (otherwise the fp32 kernel runs)
 int wn_gemm_rows16_ok(const WnGemmArgs& a) {
-  if (a.N % 32 != 0 || a.N < 64) return 0;
+  // (32 output channels: the image must be padded to two row tiles -- JTtot = 2, the second tile all zero -- and the
+  // kernels compute 64 columns of which the epilogue stores 32: the products are not what bounds these launches)
+  if (a.N % 32 != 0 || (a.N < 64 && a.JTtot < 2)) return 0;
   if (!a.vec_out) return 0;
   for (int s = 0; s < a.nseg; ++s) {
     if (a.seg[s].K % 16 != 0 || !a.seg[s].vec) return 0;
@@ -870,10 +872,13 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
     return WN_OK;
   }
   // knob 2 = 1 disables the resident form
-  if (jt_need == 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1 &&
+  if (jt_need <= 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1 &&
       nks % WnG16R<2>::PF == 0 &&
       a.seg[0].plane_k == 0) {
-    if (a.epi == WN_EPI_GATE_BWD && !a.addc)
+    // (the forms that fetch their epilogue operands ahead read all 64 columns of them: not for a padded 32-column product)
+    if (jt_need == 1)
+      hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 0>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
+    else if (a.epi == WN_EPI_GATE_BWD && !a.addc)
       hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 2>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
     else if (a.epi == WN_EPI_PLAIN && a.addc)
       hipLaunchKernelGGL((wn_gemm_rows16_resident_kernel<2, 1>), dim3((unsigned)gx, 1), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);

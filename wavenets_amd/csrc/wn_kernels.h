@@ -115,7 +115,7 @@ struct WnWgLayer {
 };
 int wn_wgrad_layer_supported(int R, int D, int KS);
 int wn_launch_wgrad_layers(const WnWgLayer* d_layers, int nlayers, int R, float* ws, float* slab, int64_t P, int B,
-                           int T, int splits_per_b, hipStream_t s);
+                           int T, int splits_per_b, hipStream_t s, int inner = 0);
 // one tap of a block's weight gradient as a staged workgroup job (wn_wgrad_pair.hip)
 struct WnWgPair {
   int64_t x_off, g_off;            // workspace offsets of X [rows][K] and G [rows][N]

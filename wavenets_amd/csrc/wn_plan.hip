@@ -50,6 +50,10 @@ struct BlockInfo {
   int64_t f16gate = -1; // fp16 split image of the gated conv with row tiles ordered [f f g g] per 64 channels, or -1
   int64_t f16nat = -1;  // fp16 split image of the gated conv in natural row-tile order for the streamed one-kernel forward (R = D = 128), or -1
   int64_t g16uf = -1;   // fp16 split image [W_r | V(b)], V(b) = W_s(b) W_f0 (skip path folded into the first head conv), or -1
+  // stacks deeper than 1 (training passes): forward images of the non-gated convs, backward-data images of every conv of
+  // the stack; 32-channel outputs are padded to two row tiles (see wn_gemm_rows16_ok)
+  int64_t d16F[16], d16B[16];
+  BlockInfo() { for (int i = 0; i < 16; ++i) d16F[i] = d16B[i] = -1; }
 };
 
 }  // namespace
@@ -84,6 +88,7 @@ struct wn_plan {
   WnTensorDesc* d_tdesc = nullptr;
   WnTensorDesc* d_kdesc = nullptr;
   bool fused_ok = false, fused16_ok = false;
+  bool deep16_ok = false;      // layers_per_block > 1: split-precision images of the whole stack exist
   float drop_rate = 0.f;        // Dropout rate applied to every block input in training (src/layers.py:108-111)
   uint64_t drop_seed = 0, drop_step = 0;
   // armed by wn_plan_arm_step_sample: the next training step also draws sample_waveform(pred)
@@ -96,11 +101,14 @@ struct wn_plan {
   bool jobs_skipk = false;
   bool jobs_layerk = false;   // per-block dW_d / dW_r come from the layer weight-gradient kernel
   WnWgLayer* d_wgl = nullptr;
+  WnWgLayer* d_wgli = nullptr;  // inner convs of deeper stacks (wn_wgrad_layer_kernel<.., INNER>)
+  int n_wgli = 0;
   // per-block weight gradients as staged pair jobs (widths the per-block kernel does not cover), by kind
   WnWgPair* d_pairs = nullptr;
   int pair_first[3] = {0, 0, 0}, pair_count[3] = {0, 0, 0};
   bool jobs_pairk = false;
   bool jobs_mfused = false;             // M = Z^T dL/da of the folded skip path rides in the dW_r jobs
+  bool jobs_deep16 = false;             // inner gradients of deeper stacks carry max-abs slots (split-precision job kernel)
   int jobs_mtr = 0;                     // ... or is its own transposed-read launch over several blocks' z (kind 7 / 8; pairs index 0)
   int jobs_pair_mode = 0;               // 0: one job per tap, 1: staged both-taps job, 2: transposed-read both-taps job
   // the head layers' weight gradients as staged pair jobs (kinds 1..4) on the head's own time split
@@ -290,7 +298,7 @@ struct WsLayout {
   int64_t GZS;                          // [rows][N*D] precomputed W_s g_skip of every block, or 0
   std::vector<int64_t> XD;              // dropout: dropped copy of every block input (training)
   int64_t gxd;                          // dropout: scratch for d loss / d (dropped input)
-  int64_t absmax; int n_absmax;         // running max-abs scalars: GF[i] | g_skipsum | GU[b] | GH[b]
+  int64_t absmax; int n_absmax;         // running max-abs scalars: GF[i] | g_skipsum | GU[b] | GH[b] | GP[b][i]
   int64_t fwd_absmax;                   // forward range guard: running max-abs of H[b], skip sum, head activations
   int64_t sum_scratch;
   std::vector<int64_t> M;               // mapping activations [B][w]
@@ -328,6 +336,12 @@ int count_jobs(const wn_plan* p) {
 // Training passes fold the skip path into the head's first convolution when the plan has the images for it
 // (fold_F0 > 0: depth-1 blocks with skip convs feeding a head whose first conv is narrower than the skip width) and the
 // split-precision kernels run; knob 21 = 1 keeps the reference's two-step form (skip sum, then the head conv).
+// stacks deeper than 1 conv, TRAINING passes only: every conv of the stack on the split-precision kernels
+// (knob 18 = 1: the exact-fp32 composed kernels, as inference and generation run them)
+bool deep16(const wn_plan* p) {
+  return p->deep16_ok && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(17) != 1 && wn_debug_get(18) != 1;
+}
+
 bool fold_ok(const wn_plan* p) {
   // (knob 15 = 1 drops the last block's zero output gradient; the folded g_u product has no one-segment form without it)
   return p->fold_F0 > 0 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(21) != 1 && wn_debug_get(4) != 1 &&
@@ -384,7 +398,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
   L.yt = cv.take(rows);
   L.sum_scratch = cv.take(2048 + 64);
   L.GZS = 0;
-  L.n_absmax = (int)p->finals.size() + 1 + p->N + (p->N + 1);
+  L.n_absmax = (int)p->finals.size() + 1 + p->N + (p->N + 1) + p->N * (p->LPB - 1);   // ... | GP[b][i] (deep stacks)
   L.absmax = cv.take(L.n_absmax);
   L.fwd_absmax = cv.take(1);
   // conditioning
@@ -618,6 +632,10 @@ struct BlockPtrs {
   const float* G16uf;                     // [W_r | V(b)]: skip path folded into the first head conv (training), or null
   const float* F16g;                      // gated conv, row tiles [f f g g] per 64 channels (composed split-precision forward), or null
   const float* F16n;                      // gated conv, natural row-tile order, for the streamed one-kernel forward (R = D = 128), or null
+  // depth > 1, training passes (set by deep16_ptrs): split-precision images of the non-gated convs (forward) and of every
+  // conv's backward-data product; JTi / JTb = row tiles of those images (32-wide outputs are padded to 2)
+  const float* F16i[16]; const float* G16i[16];
+  int JTi[16], JTb[16], JTu;
 };
 
 struct BlockBufs {
@@ -641,8 +659,10 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
   int rc;
   if (f.pre_done && k.depth > 1) { h = nullptr; hc = k.D; }
   for (int i = 0; i + 1 < k.depth && !f.pre_done; ++i) {
-    Gemm g(k.B, k.T, k.D, ceil32(k.D));
-    for (int t = 0; t < k.KS; ++t) g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[i], k.Fd[i] + t * k.Fd_stride[i]);
+    const bool i16 = k.F16i[i] != nullptr;            // (training passes of deep stacks: split-precision, see deep16_ptrs)
+    Gemm g(k.B, k.T, k.D, i16 ? k.JTi[i] : ceil32(k.D));
+    for (int t = 0; t < k.KS; ++t) g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[i], i16 ? nullptr : k.Fd[i] + t * k.Fd_stride[i]);
+    if (i16) g.w16(k.F16i[i]);
     rc = g.bias(k.bd[i]).act(k.act).run(f.P[i], k.D, s);
     if (rc) return rc;
     h = f.P[i]; hc = k.D;
@@ -739,6 +759,7 @@ struct BlockGrads {
   bool defer;               // weight gradients are computed later by the batched job table
   const float* am_gxout; const float* am_gskip;   // running max-abs of g_xout / g_skip (or null)
   float* am_gu; float* am_gx;                      // where to publish max-abs of g_u / g_x (or null)
+  float* am_gp[16];                                // ... of the kept inner gradients g_pi[i] (deep stacks in training), or null
   const float* gzs; int ld_gzs;                    // precomputed W_s g_skip slice of this block, or null
   const float* g_fold; int fold_F0; const float* am_gfold;   // folded skip path: dL/da of the first head conv [rows][F0] replaces g_skip
   float drop_rate; uint32_t drop_key; float* g_xd;  // dropout on the block input: mask the conv-path gradient
@@ -763,13 +784,17 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
   }
   // g_u = gate'( W_r g_o + W_s g_skip )
   {
-    Gemm gm(k.B, k.T, k.D, ceil32(k.D));
+    // (deep stacks in training: the [W_r | W_s] image may be padded to two row tiles; it is only set when it will be used)
+    const bool full_u = (k.S > 0) ? (g_o && g.g_skip) : (g_o != nullptr);
+    const bool pad_u = k.JTu > 0 && k.G16u && full_u && k.Cc == 0 && g.am_gu &&
+                       ((g_o == g.g_xout) ? g.am_gxout : (g_o == g.g_skip ? g.am_gskip : g.am_gxout)) != nullptr;
+    Gemm gm(k.B, k.T, k.D, pad_u ? k.JTu : ceil32(k.D));
     const bool use_gzs = g.gzs && g_o && k.G16r && g.am_gu && g.am_gxout && k.Cc == 0;
     const bool use_fold = g.g_fold && g_o && k.G16uf && g.am_gu && g.am_gxout && g.am_gfold && k.Cc == 0;
-    if (g_o) gm.seg(g_o, k.R, k.R, 0, use_fold ? nullptr : k.Br_);
+    if (g_o) gm.seg(g_o, k.R, k.R, 0, (use_fold || pad_u) ? nullptr : k.Br_);
     if (use_fold) gm.seg(g.g_fold, g.fold_F0, g.fold_F0, 0, nullptr).w16(k.G16uf).absmax(g.am_gxout, g.am_gfold, g.am_gu);
     else if (use_gzs) gm.addc(g.gzs, g.ld_gzs).w16(k.G16r).absmax(g.am_gxout, nullptr, g.am_gu);
-    else if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, k.Bs);
+    else if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, pad_u ? nullptr : k.Bs);
     if (use_gzs || use_fold) {
       rc = gm.gate_bwd(f.AG, k.D, f.Z, f.ldz).run(g.g_u, 2 * k.D, s);
     } else if (gm.a.nseg == 0) {
@@ -777,7 +802,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     } else {
       // the [W_r | W_s] image matches the segment list only when both (or, for S == 0, the single) operands exist
       const bool full = (k.S > 0) ? (g_o && g.g_skip) : true;
-      if (k.G16u && full && k.Cc == 0) {
+      if (k.G16u && full && k.Cc == 0 && (k.JTu == 0 || pad_u)) {
         const float* a0 = (g_o == g.g_xout) ? g.am_gxout : (g_o == g.g_skip ? g.am_gskip : g.am_gxout);
         const float* a1 = (k.S > 0 || g_o == g.g_o_tmp) ? g.am_gskip : nullptr;
         if (g.am_gu && a0) gm.w16(k.G16u).absmax(a0, a1, g.am_gu);
@@ -833,12 +858,18 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     }
     const bool need_gx = (i > 0) || g.g_x;
     if (!need_gx) break;
-    Gemm gm(k.B, k.T, hc, ceil32(hc));
+    // deep stacks in training: split-precision product, operand scaled by the running max-abs of gcur, the result's
+    // max-abs published for the next product and for the weight-gradient jobs
+    const float* am_cur = (i == li) ? g.am_gu : g.am_gp[i];
+    float* am_dst = (i > 0) ? g.am_gp[i - 1] : g.am_gx;
+    const bool b16 = k.depth > 1 && k.G16i[i] && am_cur && am_dst;
+    Gemm gm(k.B, k.T, hc, b16 ? k.JTb[i] : ceil32(hc));
     for (int t = 0; t < k.KS; ++t)
-      gm.seg(gcur, gc, gc, -(k.KS - 1 - t) * k.dil[i], k.Bd[i] + t * k.Bd_stride[i]);
+      gm.seg(gcur, gc, gc, -(k.KS - 1 - t) * k.dil[i], b16 ? nullptr : k.Bd[i] + t * k.Bd_stride[i]);
     if (i > 0) {
       // output is the gradient w.r.t. P[i-1] (post-activation) -> fold act' in
       float* dst = g.g_pi[i - 1] ? g.g_pi[i - 1] : g.g_p + (int64_t)((i & 1) ? 0 : rows * k.D);
+      if (b16) gm.w16(k.G16i[i]).absmax(am_cur, nullptr, am_dst);
       rc = gm.dact(f.P[i - 1], k.D, k.act).run(dst, k.D, s);
       if (rc) return rc;
       gcur = dst; gc = k.D;
@@ -846,6 +877,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
       if (g.drop_rate > 0.f) {
         // conv-path gradient first, then the keep-mask, then the (unmasked) residual path
         if (k.G16x && k.depth == 1 && g.am_gu) gm.w16(k.G16x).absmax(g.am_gu, nullptr, nullptr);
+        else if (b16) gm.w16(k.G16i[0]).absmax(am_cur, nullptr, nullptr);      // (the dropout kernel publishes g_x's max-abs)
         rc = gm.run(g.g_xd, hc, s);
         if (rc) return rc;
         rc = wn_launch_dropout(g.g_xd, (k.residual && g.g_xout) ? g.g_xout : nullptr, g.g_x, rows * hc, g.drop_rate,
@@ -855,6 +887,7 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
       }
       if (k.residual && g.g_xout) gm.addc(g.g_xout, k.R);
       if (k.G16x && k.depth == 1 && g.am_gu && g.am_gx) gm.w16(k.G16x).absmax(g.am_gu, nullptr, g.am_gx);
+      else if (b16) gm.w16(k.G16i[0]).absmax(am_cur, nullptr, am_dst);
       rc = gm.run(g.g_x, hc, s);
       if (rc) return rc;
     }
@@ -1038,6 +1071,35 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
       add_piece16(p, p->frag16_skipF, p->Sh, p->tensors[src.kernel_t].off, p->D, p->Sh, 1, b * (p->D / 16));
     }
   }
+  // Stacks deeper than 1 conv (layers_per_block > 1; the reference's default network is 5 x 5, train.py:31-49): training
+  // passes run every conv of the stack, forward and backward, on the split-precision kernels.  Widths of 32 are padded
+  // to two row tiles.  (Inference and generation keep the exact-fp32 composed kernels: the queued sampler reproduces them
+  // bit for bit.)
+  if (p->LPB > 1 && p->fused16_ok && p->R == p->D && p->R % 32 == 0 && p->Dp == p->D && (p->S == 0 || m16(p->S))) {
+    auto padded = [&](int I, int K) { return new_image16(p, std::max(I, 64), K); };
+    auto jt_of = [&](int I) { return std::max(2, ceil32(I)); };
+    for (BlockInfo& bi : p->blocks) {
+      for (int i = 0; i < p->LPB; ++i) {
+        const ConvInfo& c = bi.dil[i];
+        if (i + 1 < p->LPB) {                      // forward: A[n][tap * cin + k] = W[tap][k][n]
+          bi.d16F[i] = padded(c.cout, p->KS * c.cin);
+          for (int t = 0; t < p->KS; ++t)
+            add_piece16(p, bi.d16F[i], c.cout, p->tensors[c.kernel_t].off + (int64_t)t * c.cin * c.cout, c.cin, c.cout, 1,
+                        t * (c.cin / 16), 0, jt_of(c.cout));
+        }
+        // backward data: A[k][tap * cout + n] = W[tap][k][n]
+        bi.d16B[i] = padded(c.cin, p->KS * c.cout);
+        for (int t = 0; t < p->KS; ++t)
+          add_piece16(p, bi.d16B[i], c.cin, p->tensors[c.kernel_t].off + (int64_t)t * c.cin * c.cout, c.cout, c.cout, 0,
+                      t * (c.cout / 16), 0, jt_of(c.cin));
+      }
+      // d z = W_r g_o + W_s g_skip : image [W_r | W_s], I = D
+      bi.g16u = padded(p->D, p->R + p->S);
+      add_piece16(p, bi.g16u, p->D, p->tensors[bi.conv1.kernel_t].off, p->R, p->R, 0, 0, 0, jt_of(p->D));
+      if (bi.has_skip) add_piece16(p, bi.g16u, p->D, p->tensors[bi.conv_skip.kernel_t].off, p->S, p->S, 0, p->R / 16, 0, jt_of(p->D));
+    }
+    p->deep16_ok = true;
+  }
   if (p->LPB == 1 && m32(p->D) && m16(p->R) && (p->S == 0 || m16(p->S))) {
     for (BlockInfo& bi : p->blocks) {
       // d z = W_r g_o + W_s g_skip : image [W_r | W_s], I = D
@@ -1113,6 +1175,7 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_jobs) (void)hipFree(p->d_jobs);
   if (p->d_cov) (void)hipFree(p->d_cov);
   if (p->d_wgl) (void)hipFree(p->d_wgl);
+  if (p->d_wgli) (void)hipFree(p->d_wgli);
   if (p->d_pairs) (void)hipFree(p->d_pairs);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -1264,7 +1327,8 @@ extern "C" int wn_plan_describe(const wn_plan* p, char* buf, int32_t len) {
   if (!p || !buf || len < 1) return WN_E_INVALID;
   const bool exact = wn_debug_get(1) == 1;
   const char* fwd;
-  if (p->LPB > 1) fwd = "composed per conv (rows GEMM fp32 + fused fp32 kernel for the gated conv where the shape allows)";
+  if (p->LPB > 1 && deep16(p)) fwd = "per conv of the stack, split precision in training passes (rows contractions + the fused block kernel for the gated conv)";
+  else if (p->LPB > 1) fwd = "composed per conv (rows GEMM fp32 + fused fp32 kernel for the gated conv where the shape allows)";
   else if (!exact && p->fused16_ok) fwd = "fused split-precision block kernel, weights LDS-resident (wn_layer_fwd_f16_kernel)";
   else if (!exact && !p->blocks.empty() && p->blocks[0].f16nat >= 0 && wn_debug_get(11) == 0)
     fwd = "fused split-precision block kernel, weights streamed through an LDS ring (wn_layer_fwd_s128_kernel)";
@@ -1285,6 +1349,9 @@ extern "C" int wn_plan_describe(const wn_plan* p, char* buf, int32_t len) {
   else bwd = "two exact-fp32 rows contractions per block";
   const char* wg;
   if (!deferred) wg = "per-call split-K products (wn_wgrad_kernel) + reduces";
+  else if (p->LPB > 1 && deep16(p) && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(8) != 1)
+    wg = "one workgroup per (conv, utterance, time range): the last conv + 1x1 of a block as for depth 1, inner convs through the kernel's INNER form (wn_wgrad_layer_kernel)";
+  else if (p->LPB > 1 && deep16(p)) wg = "generic batched job table, split precision, every conv of every stack in one launch (wn_wgrad_batched_kernel)";
   else if (p->LPB > 1) wg = "generic batched job table in exact fp32, every conv of every stack in one launch (wn_wgrad_batched_kernel)";
   else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(8) != 1 && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R)
     wg = "one workgroup per (block, utterance, time range) for dW_d, db_d, dW_r, db_r (wn_wgrad_layer_kernel)";
@@ -1364,11 +1431,23 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   if (p->fused16_ok && p->LPB == 1) { k.F16d = fragbase + bi.dil.back().frag16; k.F16r = fragbase + bi.conv1.frag16; }
   if (bi.f16gate >= 0) { k.F16g = fragbase + bi.f16gate; k.F16r = fragbase + bi.conv1.frag16; }
   if (bi.f16nat >= 0) k.F16n = fragbase + bi.f16nat;
-  if (bi.g16u >= 0) k.G16u = fragbase + bi.g16u;
+  if (bi.g16u >= 0 && p->LPB == 1) k.G16u = fragbase + bi.g16u;
   if (bi.g16r >= 0) k.G16r = fragbase + bi.g16r;
   if (bi.g16uf >= 0) k.G16uf = fragbase + bi.g16uf;
   if (p->LPB == 1 && bi.dil[0].frag16B >= 0) k.G16x = fragbase + bi.dil[0].frag16B;
   return k;
+}
+
+void deep16_ptrs(const wn_plan* p, int b, const float* fragbase, BlockPtrs& k) {
+  if (!deep16(p)) return;
+  const BlockInfo& bi = p->blocks[b];
+  k.F16d = fragbase + bi.dil.back().frag16; k.F16r = fragbase + bi.conv1.frag16;
+  for (int i = 0; i < p->LPB; ++i) {
+    const ConvInfo& c = bi.dil[i];
+    if (bi.d16F[i] >= 0) { k.F16i[i] = fragbase + bi.d16F[i]; k.JTi[i] = std::max(2, ceil32(c.cout)); }
+    if (bi.d16B[i] >= 0) { k.G16i[i] = fragbase + bi.d16B[i]; k.JTb[i] = std::max(2, ceil32(c.cin)); }
+  }
+  if (bi.g16u >= 0) { k.G16u = fragbase + bi.g16u; k.JTu = std::max(2, ceil32(p->D)); }
 }
 
 struct FwdCtx {
@@ -1512,6 +1591,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   if (stack_prof) (void)hipEventRecord(p->stack_ev[p->stack_used], s);
   for (int b = 0; b < p->N; ++b) {
     BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
+    if (training && !rings) deep16_ptrs(p, b, fragbase, k);
     if (p->c.cond_inputs > 0) k.cb = ws + L.cb + (int64_t)b * B * 2 * p->D;
     BlockBufs f;
     memset(&f, 0, sizeof(f));
@@ -1657,7 +1737,9 @@ bool skip_kernel_ok(const wn_plan* p) {
 int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool skipk = skip_kernel_ok(p);
   // knob 8 = 1 keeps the per-block weight gradients on the generic job table
-  const bool layerk = p->LPB == 1 && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1 &&
+  // (stacks deeper than 1 in split-precision training, deep16: the last conv + the 1x1 as for depth 1, every inner conv
+  // through the kernel's INNER form)
+  const bool layerk = (p->LPB == 1 || deep16(p)) && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1 &&
                       wn_debug_get(3) != 1 && wn_debug_get(8) != 1;
   // knob 13 = 1 keeps them on the generic job table
   const bool pairk = !layerk && p->LPB == 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
@@ -1680,10 +1762,11 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
   // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
   const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
+  const bool d16 = deep16(p);
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_mfused == mfused && p->jobs_mtr == mtr && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
-  std::vector<WnWgLayer> wgl;
+      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_mfused == mfused && p->jobs_mtr == mtr && p->jobs_deep16 == d16 && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
+  std::vector<WnWgLayer> wgl, wgli;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
   std::vector<WnWgJob> jobs;
@@ -1694,6 +1777,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const int64_t am_skip = L.absmax + nfin;
   auto am_GU = [&](int b) { return L.absmax + nfin + 1 + b; };
   auto am_GH = [&](int b) { return L.absmax + nfin + 1 + p->N + b; };
+  auto am_GP = [&](int b, int i) { return d16 ? L.absmax + nfin + 1 + p->N + (p->N + 1) + (int64_t)b * (p->LPB - 1) + i : (int64_t)-1; };
   // input causal conv: x = inputs (B,T,1), g = d loss / d H[0]
   if (!inconvk)
     for (int t = 0; t < p->KS; ++t)
@@ -1703,11 +1787,25 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   cover(p->causal.kernel_t); cover(p->causal.bias_t);
   for (int b = 0; b < p->N; ++b) {
     const BlockInfo& bi = p->blocks[b];
-    const ConvInfo& c = bi.dil[0];
+    const ConvInfo& c = bi.dil.back();
     const int64_t zoff = L.Z + (int64_t)b * B * T * p->Dp;      // block-major Z
     if (layerk) {
+      const int64_t xin0 = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
+      for (int i = 0; i + 1 < p->LPB; ++i) {                     // inner convs of a deeper stack
+        const ConvInfo& ci = bi.dil[i];
+        WnWgLayer w;
+        memset(&w, 0, sizeof(w));
+        w.x_off = i == 0 ? xin0 : L.P[b][i - 1];
+        w.du_off = L.GP[b][i];
+        w.dwd_off = p->tensors[ci.kernel_t].off; w.dbd_off = p->tensors[ci.bias_t].off;
+        w.dwr_off = w.dbr_off = -1; w.z_off = w.go_off = 0;
+        w.gmax_u_off = am_GP(b, i); w.gmax_h_off = -1;
+        w.dilation = ci.dil; w.ldz = p->Dp;
+        wgli.push_back(w);
+        cover(ci.kernel_t); cover(ci.bias_t);
+      }
       WnWgLayer w;
-      w.x_off = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
+      w.x_off = p->LPB > 1 ? L.P[b][p->LPB - 2] : xin0;
       w.du_off = L.GU[b]; w.z_off = zoff; w.ldz = p->Dp;
       w.go_off = p->S == 0 ? L.GO[b] : L.GH[b + 1];
       w.dwd_off = p->tensors[c.kernel_t].off; w.dbd_off = p->tensors[c.bias_t].off;
@@ -1761,7 +1859,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       for (int t = 0; t < p->KS; ++t)
         add_jobs(jobs, xo, kc, kc, (p->KS - 1 - t) * ci.dil, lastc ? L.GU[b] : L.GP[b][i], nc, nc,
                  p->tensors[ci.kernel_t].off + (int64_t)t * kc * nc,
-                 t == p->KS - 1 ? p->tensors[ci.bias_t].off : -1, lastc ? am_GU(b) : -1);
+                 t == p->KS - 1 ? p->tensors[ci.bias_t].off : -1, lastc ? am_GU(b) : am_GP(b, i));
       if (!lastc) { cover(ci.kernel_t); cover(ci.bias_t); }
     }
     // S == 0: g_o = g_xout + g_skip (or a copy of g_skip): bounded by twice the larger max-abs -> no slot
@@ -1827,6 +1925,12 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     WN_HIP_CHECK(hipMalloc((void**)&p->d_wgl, wgl.size() * sizeof(WnWgLayer)));
     WN_HIP_CHECK(hipMemcpy(p->d_wgl, wgl.data(), wgl.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
   }
+  if (p->d_wgli) { (void)hipFree(p->d_wgli); p->d_wgli = nullptr; }
+  p->n_wgli = (int)wgli.size();
+  if (!wgli.empty()) {
+    WN_HIP_CHECK(hipMalloc((void**)&p->d_wgli, wgli.size() * sizeof(WnWgLayer)));
+    WN_HIP_CHECK(hipMemcpy(p->d_wgli, wgli.data(), wgli.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
+  }
   if (p->d_pairs) { (void)hipFree(p->d_pairs); p->d_pairs = nullptr; }
   {
     std::vector<WnWgPair> all;
@@ -1845,7 +1949,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_mfused = mfused; p->jobs_mtr = mtr; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_mfused = mfused; p->jobs_mtr = mtr; p->jobs_deep16 = d16; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
   p->jobs_fold = fold;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
@@ -1959,6 +2063,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   float* am_gskip = am + nf;
   auto am_GU = [&](int b) { return am + nf + 1 + b; };
   auto am_GH = [&](int b) { return am + nf + 1 + p->N + b; };
+  auto am_GP = [&](int b, int i) { return am + nf + 1 + p->N + (p->N + 1) + b * (p->LPB - 1) + i; };
   if (phases & 1) {
   WN_HIP_CHECK(hipMemsetAsync(am, 0, L.n_absmax * sizeof(float), s));
   rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s);
@@ -2077,6 +2182,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
                        wn_debug_get(15) != 1;
     for (int b = p->N - 1; b >= 0; --b) {
       BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
+      deep16_ptrs(p, b, fragbase, k);
       const BlockInfo& bi = p->blocks[b];
       if (pairk && b < p->N - 1) {
         const BlockPtrs k1 = block_ptrs(p, b + 1, params, fragbase, B, T);
@@ -2113,6 +2219,8 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       memset(&bg, 0, sizeof(bg));
       bg.defer = true;
       for (int i = 0; i + 1 < p->LPB; ++i) bg.g_pi[i] = ws + L.GP[b][i];
+      if (deep16(p))
+        for (int i = 0; i + 1 < p->LPB; ++i) bg.am_gp[i] = am_GP(b, i);
       if (p->drop_rate > 0.f) {
         bg.drop_rate = p->drop_rate; bg.drop_key = wn_dropout_key(p->drop_seed, b, p->drop_step); bg.g_xd = ws + L.gxd;
       }
@@ -2176,7 +2284,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     }
     const bool head_own = L.hsplits > 0 && (p->head_first < p->njobs || p->jobs_headpairs);
     rc = wn_launch_wgrad_batched(p->d_jobs, head_own ? p->head_first : p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits,
-                                 fork ? p->side : s, p->LPB > 1 && wn_debug_get(18) != 1);
+                                 fork ? p->side : s, p->LPB > 1 && !p->jobs_deep16);
     if (rc) return rc;
     if (head_own) {
       // job and coverage offsets are offsets into the flat parameter buffer: the compact slab is addressed
@@ -2214,6 +2322,8 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       }
     if (p->jobs_layerk) {
       rc = wn_launch_wgrad_layers(p->d_wgl, p->N, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
+      if (rc) return rc;
+      rc = wn_launch_wgrad_layers(p->d_wgli, p->n_wgli, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s, 1);
       if (rc) return rc;
     }
     if (fold) {

@@ -3,6 +3,8 @@
 //   dW_d[tap][k][n] = sum_t x[t - (1 - tap) d][k] * du[t][n]      (KS = 2)
 //   dW_r[k][n]      = sum_t z[t][k] * go[t][n]
 //   db_d[n] = sum_t du[t][n],  db_r[n] = sum_t go[t][n]
+// INNER instantiations (round 3): a non-gated conv of a stack deeper than 1 (src/layers.py:66-80, layers_per_block > 1):
+// the same x[t-d] | x[t] staging against an output gradient of R channels, no 1x1 part.
 // The generic batched kernel (wn_gemm.hip) runs one wave per (tap, K block, N block) job: every job
 // re-reads and re-splits its operands (7.9 GB of loads per step at configs[1]) and waits on them.
 // Here a workgroup of 4 waves owns (block, utterance, time range).  Per chunk of 16 time steps each
@@ -36,15 +38,19 @@ __device__ __forceinline__ void wl_scale_from_max(const float* slot, float& sc, 
 
 }  // namespace
 
-// C32 = R / 32 = D / 32 (1 or 2).  Channel order of a stage: x[t-d] (R) | x[t] (R) | du (2D) | z (D) | go (R)
-template <int C32>
+// C32 = R / 32 = D / 32 (1 or 2).  Channel order of a stage: x[t-d] (R) | x[t] (R) | du (2D) | z (D) | go (R);
+// INNER: x[t-d] (R) | x[t] (R) | du (R)
+template <int C32, bool INNER>
 __global__ __launch_bounds__(256, 2) void wn_wgrad_layer_kernel(const WnWgLayer* layers, float* ws, float* slab,
                                                                 int64_t P, int B, int T, int spb) {
-  constexpr int R = 32 * C32, NCH = 6 * R;
-  constexpr int NU = 1 + (2 * 4 * R + 255) / 256;       // one du unit + the stride-R units of a thread
+  constexpr int R = 32 * C32, NCH = INNER ? 3 * R : 6 * R;
+  constexpr int DUW = INNER ? R : 2 * R;                // channels (= row stride) of du
+  constexpr int NXU = INNER ? 2 * 2 * R : 2 * 4 * R;    // stride-R units of a workgroup: (x[t-d] | x[t] (| z | go)) x two halves
+  constexpr int NU = 1 + (NXU + 255) / 256;             // one du unit + the stride-R units of a thread
   constexpr int PLANE = NCH * 32;                       // bytes of one fp16 plane of a stage
   constexpr int STAGE = 2 * PLANE;
-  constexpr int NJ = (C32 == 2) ? 4 : 1;                // du tiles per wave
+  // du tiles per wave.  INNER: C32 = 2: wave = x tile (tap, k tile), both du tiles; C32 = 1: waves 0, 2 own tap 0, 1
+  constexpr int NJ = INNER ? C32 : ((C32 == 2) ? 4 : 1);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * NCH * 4];
   float* bpart = reinterpret_cast<float*>(smem + 2 * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,21 +75,21 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_layer_kernel(const WnWgLayer*
   float uscale[NU];
   bool uvalid[NU], ugrad[NU];
   {
-    uvalid[0] = tid < 2 * 2 * R;
-    const int c = uvalid[0] ? tid % (2 * R) : 0;
+    uvalid[0] = tid < 2 * DUW;
+    const int c = uvalid[0] ? tid % DUW : 0;
     uch[0] = 2 * R + c;
-    uhh[0] = uvalid[0] ? tid / (2 * R) : 0;
+    uhh[0] = uvalid[0] ? tid / DUW : 0;
     ushift[0] = 0;
     uscale[0] = su;
     ugrad[0] = true;
-    uptr[0] = ws + Ld.du_off + (int64_t)ub * T * 2 * R + c;
+    uptr[0] = ws + Ld.du_off + (int64_t)ub * T * DUW + c;
   }
 #pragma unroll
   for (int i = 1; i < NU; ++i) {
     const int uid = (i - 1) * 256 + tid;
-    uvalid[i] = uid < 2 * 4 * R;
-    const int c = uvalid[i] ? uid % (4 * R) : 0;
-    uhh[i] = uvalid[i] ? uid / (4 * R) : 0;
+    uvalid[i] = uid < NXU;
+    const int c = uvalid[i] ? uid % (NXU / 2) : 0;
+    uhh[i] = uvalid[i] ? uid / (NXU / 2) : 0;
     ushift[i] = 0;
     uscale[i] = 1.0f;
     ugrad[i] = false;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_layer_kernel(const WnWgLayer*
     const bool interior = (t0 + 16 <= r1) && (t0 - d >= 0);          // workgroup-uniform
     wn_static_for<NU>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      constexpr int LD = (i == 0) ? 2 * R : R;
+      constexpr int LD = (i == 0) ? DUW : R;
       const int tb = t0 + 8 * uhh[i] - ushift[i];
       const float* p = uptr[i] + (int64_t)tb * LD;
       if (interior && uvalid[i]) {
@@ -146,8 +152,9 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_layer_kernel(const WnWgLayer*
 
   // ---- this wave's output tiles ----
   const int xt = (C32 == 2) ? wave : (wave >> 1);       // x tile (tap-major: tap = xt / C32, k tile = xt % C32)
-  const int j0 = (C32 == 2) ? 0 : (wave & 1);           // first du tile
-  const bool has_r = (C32 == 2) || wave == 0;           // owns a dW_r tile
+  const int j0 = (C32 == 2 || INNER) ? 0 : (wave & 1);  // first du tile
+  const bool has_d = !INNER || C32 == 2 || (wave & 1) == 0;   // owns dW_d tiles (INNER, C32 = 1: two tiles for four waves)
+  const bool has_r = !INNER && ((C32 == 2) || wave == 0);     // owns a dW_r tile
   const int zt = (C32 == 2) ? (wave >> 1) : 0, gt = (C32 == 2) ? (wave & 1) : 0;
   f32x16 acc[NJ], accr;
 #pragma unroll
@@ -164,9 +171,10 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_layer_kernel(const WnWgLayer*
       lo = *reinterpret_cast<const wl_h8*>(st + PLANE + cb * 32);
     };
     wl_h8 ah, al;
-    frag(32 * xt, ah, al);
+    if (has_d) frag(32 * xt, ah, al);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+      if (!has_d) break;
       wl_h8 bh, bl;
       frag(2 * R + 32 * (j0 + j), bh, bl);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_layer_kernel(const WnWgLayer*
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = 32 * kt + wn_drow(r, h);
-        row[Ld.dwd_off + ((int64_t)tap * R + k) * (2 * R) + 32 * (j0 + j) + tl] = acc[j][r] * inv_u;
+        if (has_d) row[Ld.dwd_off + ((int64_t)tap * R + k) * DUW + 32 * (j0 + j) + tl] = acc[j][r] * inv_u;
       }
     if (has_r) {
 #pragma unroll
@@ -231,19 +239,23 @@ __global__ __launch_bounds__(256, 2) void wn_wgrad_layer_kernel(const WnWgLayer*
     if (uvalid[i] && ugrad[i]) bpart[uhh[i] * NCH + uch[i]] = bsum[i];
   __syncthreads();
   for (int c = tid; c < NCH; c += 256) {
-    if (c >= 2 * R && c < 4 * R) row[Ld.dbd_off + (c - 2 * R)] = bpart[c] + bpart[NCH + c];
-    else if (c >= 5 * R) row[Ld.dbr_off + (c - 5 * R)] = bpart[c] + bpart[NCH + c];
+    if (c >= 2 * R && c < 2 * R + DUW) { if (Ld.dbd_off >= 0) row[Ld.dbd_off + (c - 2 * R)] = bpart[c] + bpart[NCH + c]; }
+    else if (!INNER && c >= 5 * R) row[Ld.dbr_off + (c - 5 * R)] = bpart[c] + bpart[NCH + c];
   }
 }
 
 int wn_wgrad_layer_supported(int R, int D, int KS) { return R == D && (R == 32 || R == 64) && KS == 2; }
 
+// inner: every entry is a non-gated conv of a deeper stack (x_off, du_off = its output gradient [rows][R], dwd_off, dbd_off,
+// gmax_u_off, dilation; the 1x1 fields are ignored)
 int wn_launch_wgrad_layers(const WnWgLayer* d_layers, int nlayers, int R, float* ws, float* slab, int64_t P, int B,
-                           int T, int splits_per_b, hipStream_t s) {
+                           int T, int splits_per_b, hipStream_t s, int inner) {
   if (nlayers <= 0) return WN_OK;
   const dim3 grid((unsigned)(B * splits_per_b), (unsigned)nlayers);
-  if (R == 64) hipLaunchKernelGGL(wn_wgrad_layer_kernel<2>, grid, dim3(256), 0, s, d_layers, ws, slab, P, B, T, splits_per_b);
-  else if (R == 32) hipLaunchKernelGGL(wn_wgrad_layer_kernel<1>, grid, dim3(256), 0, s, d_layers, ws, slab, P, B, T, splits_per_b);
+  if (R == 64 && inner) hipLaunchKernelGGL((wn_wgrad_layer_kernel<2, true>), grid, dim3(256), 0, s, d_layers, ws, slab, P, B, T, splits_per_b);
+  else if (R == 32 && inner) hipLaunchKernelGGL((wn_wgrad_layer_kernel<1, true>), grid, dim3(256), 0, s, d_layers, ws, slab, P, B, T, splits_per_b);
+  else if (R == 64) hipLaunchKernelGGL((wn_wgrad_layer_kernel<2, false>), grid, dim3(256), 0, s, d_layers, ws, slab, P, B, T, splits_per_b);
+  else if (R == 32) hipLaunchKernelGGL((wn_wgrad_layer_kernel<1, false>), grid, dim3(256), 0, s, d_layers, ws, slab, P, B, T, splits_per_b);
   else { wn_set_error("wgrad_layers: unsupported width %d", R); return WN_E_UNSUPPORTED; }
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
