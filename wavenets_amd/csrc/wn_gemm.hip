@@ -629,9 +629,51 @@ __global__ void wn_reduce_table_kernel(const float* slab, int nsplit, int64_t P,
   }
 }
 
+// The same sums with one element per thread and exactly as many workgroups as the tensors need: the grid above is
+// (64, tensors) whatever their lengths -- 11 520 workgroups at configs[1], most of which find nothing to do (42 us), and
+// 15 serial elements per thread for the one long tensor of the folded skip path.  bf.v[t] = first workgroup of tensor t.
+struct WnBlkFirst { int v[257]; };
+__global__ __launch_bounds__(256) void wn_reduce_flat_kernel(const float* slab, int nsplit, int64_t P, float* out,
+                                                             const WnTensorDesc* table, WnBlkFirst bf, int n) {
+  int lo = 0, hi = n;                                   // largest t with bf.v[t] <= blockIdx.x (workgroup-uniform)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (bf.v[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const WnTensorDesc d = table[lo];
+  const int64_t i = (int64_t)((int)blockIdx.x - bf.v[lo]) * 256 + threadIdx.x;
+  if (i >= d.len) return;
+  // rows requested 16 at a time, added in row order (the sum is the same as one by one)
+  float acc = 0.f;
+  const float* col = slab + d.off + i;
+  int s = 0;
+  for (; s + 16 <= nsplit; s += 16) {
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = col[(int64_t)(s + e) * P];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc += v[e];
+  }
+  for (; s < nsplit; ++s) acc += col[(int64_t)s * P];
+  out[d.off + i] = acc;
+}
+
+// h_table: host copy of the same n descriptors (or null: the (64, n) grid)
 int wn_launch_reduce_table(const float* slab, int nsplit, int64_t P, float* out, const WnTensorDesc* d_table,
-                           int n, hipStream_t s) {
+                           int n, hipStream_t s, const WnTensorDesc* h_table) {
   if (n <= 0) return WN_OK;
+  if (h_table && n <= 256) {
+    WnBlkFirst bf;
+    int64_t nblk = 0;
+    for (int t = 0; t < n; ++t) { bf.v[t] = (int)nblk; nblk += (h_table[t].len + 255) / 256; }
+    for (int t = n; t <= 256; ++t) bf.v[t] = (int)nblk;
+    if (nblk <= 0) return WN_OK;
+    if (nblk < (int64_t)1 << 30) {
+      hipLaunchKernelGGL(wn_reduce_flat_kernel, dim3((unsigned)nblk), dim3(256), 0, s, slab, nsplit, P, out, d_table, bf, n);
+      WN_HIP_CHECK(hipGetLastError());
+      return WN_OK;
+    }
+  }
   hipLaunchKernelGGL(wn_reduce_table_kernel, dim3(64, n), dim3(256), 0, s, slab, nsplit, P, out, d_table);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;

@@ -164,7 +164,7 @@ int wn_wgrad_tile_n();
 int wn_launch_wgrad_batched(const WnWgJob* d_jobs, int njobs, float* ws, float* slab, int64_t P, int B, int T,
                             int splits_per_b, hipStream_t s, bool exact_fp32 = false);
 int wn_launch_reduce_table(const float* slab, int nsplit, int64_t P, float* out, const WnTensorDesc* d_table,
-                           int n, hipStream_t s);
+                           int n, hipStream_t s, const WnTensorDesc* h_table = nullptr);
 // out[(k / seg_len) * seg_stride + (k % seg_len) * N + n] (+)= sum_s slab[s][k][n]
 struct WnReduceArgs {
   const float* slab; int32_t nsplit; int32_t K; int32_t N;

@@ -81,6 +81,8 @@ struct wn_plan {
   std::vector<WnPrepDesc> prep2;
   WnPrepDesc* d_prep2 = nullptr;
   WnTensorDesc* d_cov_fold = nullptr;
+  WnTensorDesc h_cov_fold = {0, 0};     // host copies of the coverage tables (the flattened reduce sizes its grid from them)
+  std::vector<WnTensorDesc> h_cov;
   std::vector<WnPrepDesc> prep;
   std::vector<WnTensorDesc> tdesc, kdesc;
   // device copies (lazy)
@@ -252,6 +254,7 @@ int ensure_device_tables(wn_plan* p) {
     d.off = 0; d.len = (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0;
     WN_HIP_CHECK(hipMalloc((void**)&p->d_cov_fold, sizeof(WnTensorDesc)));
     WN_HIP_CHECK(hipMemcpy(p->d_cov_fold, &d, sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+    p->h_cov_fold = d;
   }
   return WN_OK;
 }
@@ -1920,6 +1923,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   if (!jobs.empty()) WN_HIP_CHECK(hipMemcpy(p->d_jobs, jobs.data(), jobs.size() * sizeof(WnWgJob), hipMemcpyHostToDevice));
   WN_HIP_CHECK(hipMalloc((void**)&p->d_cov, cov.size() * sizeof(WnTensorDesc)));
   WN_HIP_CHECK(hipMemcpy(p->d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+  p->h_cov = cov;
   if (p->d_wgl) { (void)hipFree(p->d_wgl); p->d_wgl = nullptr; }
   if (!wgl.empty()) {
     WN_HIP_CHECK(hipMalloc((void**)&p->d_wgl, wgl.size() * sizeof(WnWgLayer)));
@@ -2337,7 +2341,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.GF[0], F0, rows, p->N * p->D, F0, p->D, B * L.bsplits, ws + L.mslab, pm,
                                 0, (int64_t)p->D * F0, (int64_t)p->N * p->D * F0, 0, 1, am_GF(0), s);
       if (rc) return rc;
-      rc = wn_launch_reduce_table(ws + L.mslab, B * L.bsplits, pm, ws + L.mtot, p->d_cov_fold, 1, s);
+      rc = wn_launch_reduce_table(ws + L.mslab, B * L.bsplits, pm, ws + L.mtot, p->d_cov_fold, 1, s, &p->h_cov_fold);
       if (rc) return rc;
       const BlockInfo& b0 = p->blocks[0];
       const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
@@ -2383,15 +2387,15 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     // coverage entries 0, 1 are the input conv's kernel and bias: from their compact slab when the dedicated kernel ran
     const int cov0 = p->jobs_inconvk ? 2 : 0;
     rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov + cov0,
-                                (head_own ? p->cov_head_first : p->ncov) - cov0, s);
+                                (head_own ? p->cov_head_first : p->ncov) - cov0, s, p->h_cov.data() + cov0);
     if (rc) return rc;
     if (p->jobs_inconvk) {
-      rc = wn_launch_reduce_table(ws + L.islab, B * L.isplits, (int64_t)(p->KS + 1) * p->R, grads, p->d_cov, 2, s);
+      rc = wn_launch_reduce_table(ws + L.islab, B * L.isplits, (int64_t)(p->KS + 1) * p->R, grads, p->d_cov, 2, s, p->h_cov.data());
       if (rc) return rc;
     }
     if (head_own) {
       rc = wn_launch_reduce_table(ws + L.hslab - L.head_base, B * L.hsplits, L.head_span, grads, p->d_cov + p->cov_head_first,
-                                  p->ncov - p->cov_head_first, s);
+                                  p->ncov - p->cov_head_first, s, p->h_cov.data() + p->cov_head_first);
       if (rc) return rc;
     }
     if (!p->c.use_skip && p->S > 0) {
