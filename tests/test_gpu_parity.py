@@ -939,6 +939,27 @@ def test_categorical_loss_kernel_forms_agree_bitwise():
   assert res[0][1] is not None and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize('name', ['cat_r64', 'cat_r32_f128'])
+def test_fold_weight_space_products_and_reductions_agree_bitwise(name):
+  """The folded skip path's small weight-space products on the 32 x 32-tile kernel (one round trip per 128 k) and on the
+  64 x 64-tile kernel (knob 32) run the same fma chain per element: loss and every parameter gradient are bit-identical."""
+  from wavenets_amd import _lib
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=5, bias_range=0.3, **kw)
+  x = O.synthetic_waveform(3, 700 + 1, seed=23).to(dev())
+  L = _lib.lib()
+  res = []
+  for knob in (0, 1):
+    try:
+      L.wn_debug_set(32, knob)
+      loss, _, _ = model.loss_and_grads(x)
+      res.append((loss.clone(), model.flat_grads.clone()))
+    finally:
+      L.wn_debug_set(32, 0)
+  assert torch.equal(res[0][0][:2], res[1][0][:2])
+  assert torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize('name,det', [('cat_r64', True), ('cat_r64', False), ('cat_small_fused', False), ('mol', False)])
 def test_queued_generation_launch_variants_agree(name, det):
   """The queued sampler's launch variants draw the same samples as the sliding window: the first chain kernel (knob 23),

@@ -1061,9 +1061,62 @@ __global__ __launch_bounds__(256) void wn_sgemm_small_kernel(const float* A, int
       if (i < M && j < N) C[(int64_t)i * ldc + j] = acc[a][b];
     }
 }
+// Second form: 32 x 32 tile per workgroup (four times the workgroups: 244 instead of 62 for V = W_s(all) W_f0) and K in
+// chunks of 128 whose loads are ALL in flight before the first product (one global round trip per chunk instead of one
+// per 16 k: the 64 x 64 form above spends 37 us on a 63-MFLOP product behind its 16 dependent round trips).  Same fma
+// chain per element, k ascending: the two forms agree bit for bit.
+__global__ __launch_bounds__(256) void wn_sgemm_small32_kernel(const float* A, int64_t sai, int64_t sak, const float* B, int64_t sbk,
+                                                               int64_t sbj, float* C, int ldc, int M, int N, int K) {
+  constexpr int KC = 128;
+  __shared__ float As[KC][32 + 1], Bs[KC][32 + 1];
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // outputs (ty + 8 a, tx), a < 4
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    float ra[16], rb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = threadIdx.x + 256 * q;                           // 32 x 128 elements of each operand
+      // the faster-varying index follows the operand's unit stride (coalesced either way round)
+      const int ka = sak == 1 ? e % KC : e / 32, ia = sak == 1 ? e / KC : e % 32;
+      ra[q] = (i0 + ia < M && k0 + ka < K) ? A[(int64_t)(i0 + ia) * sai + (int64_t)(k0 + ka) * sak] : 0.f;
+      const int kb = sbk == 1 ? e % KC : e / 32, jb = sbk == 1 ? e / KC : e % 32;
+      rb[q] = (j0 + jb < N && k0 + kb < K) ? B[(int64_t)(k0 + kb) * sbk + (int64_t)(j0 + jb) * sbj] : 0.f;
+    }
+    if (k0 > 0) __syncthreads();                                     // the previous chunk has been read
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = threadIdx.x + 256 * q;
+      const int ka = sak == 1 ? e % KC : e / 32, ia = sak == 1 ? e / KC : e % 32;
+      As[ka][ia] = ra[q];
+      const int kb = sbk == 1 ? e % KC : e / 32, jb = sbk == 1 ? e / KC : e % 32;
+      Bs[kb][jb] = rb[q];
+    }
+    __syncthreads();
+    // (k past the end of K is stored as zero: fma(0, 0, acc) leaves acc as it is; fixed trip count so that the LDS reads
+    // of eight k are in flight together)
+#pragma unroll 8
+    for (int k = 0; k < KC; ++k) {
+      const float bv = Bs[k][tx];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] = fmaf(As[k][ty + 8 * a], bv, acc[a]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + ty + 8 * a, j = j0 + tx;
+    if (i < M && j < N) C[(int64_t)i * ldc + j] = acc[a];
+  }
+}
 int wn_launch_sgemm_small(const float* A, int64_t sai, int64_t sak, const float* B, int64_t sbk, int64_t sbj, float* C, int ldc,
                           int M, int N, int K, hipStream_t s) {
   if (M <= 0 || N <= 0) return WN_OK;
+  if (wn_debug_get(32) != 1) {                             // knob 32 = 1: the 64 x 64 form (A/B, bit-identity test)
+    hipLaunchKernelGGL(wn_sgemm_small32_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, sai, sak, B, sbk, sbj, C,
+                       ldc, M, N, K);
+    WN_HIP_CHECK(hipGetLastError());
+    return WN_OK;
+  }
   hipLaunchKernelGGL(wn_sgemm_small_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, sai, sak, B, sbk, sbj, C, ldc,
                      M, N, K);
   WN_HIP_CHECK(hipGetLastError());

@@ -49,13 +49,14 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   24  = 1: the generation chain kernel stamps its phases with s_memtime for blocks 8..11 (wn_debug_gen_ts reads them)
 //   30  = 1: the streamed planar contraction (wn_gemm16s.hip) with one row tile per wave instead of two
 //   31  = 1: the folded skip contraction on wn_gemm_rows16_kernel (no wn_gemm_planes16s_kernel)
+//   32  = 1: the folded skip path's small weight-space products on the 64 x 64-tile kernel (no wn_sgemm_small32_kernel)
 // thread-local: a caller that switches kernel variants (the range guard's exact-fp32 retry, tools/ A/B runs, tests)
 // affects the launches of its own thread only
-static thread_local int g_wn_debug[32] = {0};
-int wn_debug_get(int key) { return (key >= 0 && key < 32) ? g_wn_debug[key] : 0; }
+static thread_local int g_wn_debug[64] = {0};
+int wn_debug_get(int key) { return (key >= 0 && key < 64) ? g_wn_debug[key] : 0; }
 extern "C" int wn_debug_value(int key) { return wn_debug_get(key); }
 extern "C" int wn_debug_set(int key, int value) {
-  if (key < 0 || key >= 32) return -1;
+  if (key < 0 || key >= 64) return -1;
   g_wn_debug[key] = value;
   return 0;
 }
