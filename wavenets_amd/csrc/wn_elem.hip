@@ -1065,10 +1065,14 @@ __global__ __launch_bounds__(256) void wn_sgemm_small_kernel(const float* A, int
 // chunks of 128 whose loads are ALL in flight before the first product (one global round trip per chunk instead of one
 // per 16 k: the 64 x 64 form above spends 37 us on a 63-MFLOP product behind its 16 dependent round trips).  Same fma
 // chain per element, k ascending: the two forms agree bit for bit.
+// blockIdx.z = batch index: operand / result bases advance by za / zb / zc floats (the conditioning convs of all blocks as
+// one launch); bias (+ activation) = the Dense epilogue of the conditioning's mapping stack (src/model.py:121-135).
 __global__ __launch_bounds__(256) void wn_sgemm_small32_kernel(const float* A, int64_t sai, int64_t sak, const float* B, int64_t sbk,
-                                                               int64_t sbj, float* C, int ldc, int M, int N, int K) {
+                                                               int64_t sbj, float* C, int ldc, int M, int N, int K,
+                                                               int64_t za, int64_t zb, int64_t zc, const float* bias, int act) {
   constexpr int KC = 128;
   __shared__ float As[KC][32 + 1], Bs[KC][32 + 1];
+  A += (int64_t)blockIdx.z * za; B += (int64_t)blockIdx.z * zb; C += (int64_t)blockIdx.z * zc;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // outputs (ty + 8 a, tx), a < 4
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1105,7 +1109,11 @@ __global__ __launch_bounds__(256) void wn_sgemm_small32_kernel(const float* A, i
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int i = i0 + ty + 8 * a, j = j0 + tx;
-    if (i < M && j < N) C[(int64_t)i * ldc + j] = acc[a];
+    if (i < M && j < N) {
+      float v = acc[a];
+      if (bias) v = wn_act(v + bias[j], act);
+      C[(int64_t)i * ldc + j] = v;
+    }
   }
 }
 int wn_launch_sgemm_small(const float* A, int64_t sai, int64_t sak, const float* B, int64_t sbk, int64_t sbj, float* C, int ldc,
@@ -1113,12 +1121,24 @@ int wn_launch_sgemm_small(const float* A, int64_t sai, int64_t sak, const float*
   if (M <= 0 || N <= 0) return WN_OK;
   if (wn_debug_get(32) != 1) {                             // knob 32 = 1: the 64 x 64 form (A/B, bit-identity test)
     hipLaunchKernelGGL(wn_sgemm_small32_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, sai, sak, B, sbk, sbj, C,
-                       ldc, M, N, K);
+                       ldc, M, N, K, (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr, 0);
     WN_HIP_CHECK(hipGetLastError());
     return WN_OK;
   }
   hipLaunchKernelGGL(wn_sgemm_small_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, sai, sak, B, sbk, sbj, C, ldc,
                      M, N, K);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+// nz products in one launch (bases za / zb / zc floats apart), optional Dense epilogue C = act(A B + bias)
+int wn_launch_sgemm_small_batched(const float* A, int64_t sai, int64_t sak, int64_t za, const float* B, int64_t sbk, int64_t sbj,
+                                  int64_t zb, float* C, int ldc, int64_t zc, int M, int N, int K, int nz, const float* bias,
+                                  int act, hipStream_t s) {
+  if (M <= 0 || N <= 0 || nz <= 0) return WN_OK;
+  if (nz > 65535) { wn_set_error("sgemm_small_batched: too many products"); return WN_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(wn_sgemm_small32_kernel, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(256), 0, s, A, sai, sak, B, sbk, sbj, C,
+                     ldc, M, N, K, za, zb, zc, bias, act);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

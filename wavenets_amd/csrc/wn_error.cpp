@@ -50,6 +50,7 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   30  = 1: the streamed planar contraction (wn_gemm16s.hip) with one row tile per wave instead of two
 //   31  = 1: the folded skip contraction on wn_gemm_rows16_kernel (no wn_gemm_planes16s_kernel)
 //   32  = 1: the folded skip path's small weight-space products on the 64 x 64-tile kernel (no wn_sgemm_small32_kernel)
+//   33  = 1: the conditioning path (mapping Dense stack, conditioning convs) as rows-GEMM launches (no small-product kernel)
 // thread-local: a caller that switches kernel variants (the range guard's exact-fp32 retry, tools/ A/B runs, tests)
 // affects the launches of its own thread only
 static thread_local int g_wn_debug[64] = {0};

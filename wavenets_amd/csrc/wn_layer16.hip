@@ -80,12 +80,14 @@ __device__ __forceinline__ void wn_store_tile(const f32x16 (&v)[C32], float* sta
 
 // FAST = the plain training / inference call (taps from x with the block's dilation, no conditioning bias,
 // residual from the newest tap, z written, no separate pre-residual output): the optional paths and
-// their registers are compiled out.  FAST == 2 additionally saves the sigmoid (training).
+// their registers are compiled out.  FAST == 2 additionally saves the sigmoid (training); FAST == 3 is FAST == 2 with the
+// per-utterance conditioning bias kept (training passes of globally conditioned networks).
 template <int R32, int D32, int KS, int FAST>
 __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs a_in) {
   WnLayerFwdArgs a = a_in;
   if constexpr (FAST > 0) {
-    a.xt[0] = a.xt[1] = a.xt[2] = nullptr; a.cb = nullptr; a.res = nullptr; a.o_out = nullptr; a.residual = 1;
+    a.xt[0] = a.xt[1] = a.xt[2] = nullptr; a.res = nullptr; a.o_out = nullptr; a.residual = 1;
+    if constexpr (FAST != 3) a.cb = nullptr;
     if constexpr (FAST == 1) a.ag_out = nullptr;
   }
   using G = WnL16<R32, D32, KS>;
@@ -278,11 +280,12 @@ int wn_launch_layer_fwd_f16(const WnLayerFwdArgs& a, hipStream_t s) {
   if (tiles <= 0) return WN_OK;
   int64_t gx = (tiles + 7) / 8;
   if (gx > 256) gx = 256;                    // one persistent workgroup per CU
-  const bool plain = !a.xt[0] && !a.xt[1] && !a.xt[2] && !a.cb && !a.res && !a.o_out && a.residual && a.z_out;
-  const int fast = (plain && a.ag_out) ? 2 : 0;       // (the inference form, FAST == 1, spills: generic kernel)
+  const bool plain = !a.xt[0] && !a.xt[1] && !a.xt[2] && !a.res && !a.o_out && a.residual && a.z_out;
+  const int fast = (plain && a.ag_out) ? (a.cb ? 3 : 2) : 0;       // (the inference form, FAST == 1, spills: generic kernel)
 #define WN_L16_LAUNCH(R32_, D32_, KS_)                                                                                      \
   do {                                                                                                                      \
     if (fast == 2) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<R32_, D32_, KS_, 2>), dim3((unsigned)gx), dim3(512), 0, s, a);      \
+    else if (fast == 3) hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<R32_, D32_, KS_, 3>), dim3((unsigned)gx), dim3(512), 0, s, a); \
     else hipLaunchKernelGGL((wn_layer_fwd_f16_kernel<R32_, D32_, KS_, 0>), dim3((unsigned)gx), dim3(512), 0, s, a);                \
   } while (0)
   if (a.R == 32 && a.KS == 2) WN_L16_LAUNCH(1, 1, 2);

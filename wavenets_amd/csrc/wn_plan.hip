@@ -345,6 +345,18 @@ bool deep16(const wn_plan* p) {
   return p->deep16_ok && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(17) != 1 && wn_debug_get(18) != 1;
 }
 
+// The conditioning path works on [B][width] matrices (B = utterances): a rows-GEMM launch per Dense / conv is one wave
+// walking its k-steps behind a global round trip each (30-250 us for a few kFLOP).  They run on the small fp32 product
+// kernel instead (wn_sgemm_small32_kernel: batched over blocks, Dense epilogue); knob 33 = 1: the rows-GEMM launches.
+bool cond_small(const wn_plan* p) {
+  if (wn_debug_get(33) == 1 || p->c.cond_inputs <= 0) return false;
+  for (int b = 1; b < p->N; ++b) {            // the blocks' conditioning convs must be evenly spaced in the flat buffer
+    const int64_t w0 = p->tensors[p->blocks[0].conv_cond.kernel_t].off, w1 = p->tensors[p->blocks[1].conv_cond.kernel_t].off;
+    if (!p->blocks[b].has_cond || p->tensors[p->blocks[b].conv_cond.kernel_t].off != w0 + (int64_t)b * (w1 - w0)) return false;
+  }
+  return p->blocks[0].has_cond;
+}
+
 bool fold_ok(const wn_plan* p) {
   // (knob 15 = 1 drops the last block's zero output gradient; the folded g_u product has no one-segment form without it)
   return p->fold_F0 > 0 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(21) != 1 && wn_debug_get(4) != 1 &&
@@ -1534,6 +1546,10 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     int mc = p->c.cond_inputs;
     for (size_t j = 0; j < p->mapping.size(); ++j) {
       const ConvInfo& c = p->mapping[j];
+      if (cond_small(p))      // Dense: M[j] = act(m W + b), W = kernel (cin, cout)
+        rc = wn_launch_sgemm_small_batched(m, mc, 1, 0, params + p->tensors[c.kernel_t].off, c.cout, 1, 0, ws + L.M[j], c.cout, 0,
+                                           B, c.cout, mc, 1, params + p->tensors[c.bias_t].off, p->c.mapping_activation, s);
+      else
       rc = Gemm(1, B, c.cout, ceil32(c.cout)).seg(m, mc, mc, 0, fragbase + c.fragF)
                .bias(params + p->tensors[c.bias_t].off).act(p->c.mapping_activation).run(ws + L.M[j], c.cout, s);
       if (rc) return rc;
@@ -1544,6 +1560,11 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
       const int D2 = 2 * p->D;
       const ConvInfo& c0 = p->blocks[0].conv_cond;
       const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.bias_t].off - p->tensors[c0.bias_t].off : 0;
+      if (cond_small(p)) {    // block z: cbt[:, z * 2D ..] = m W_c(z), W_c = kernel (1, Cc, 2D)
+        const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.kernel_t].off - p->tensors[c0.kernel_t].off : 0;
+        rc = wn_launch_sgemm_small_batched(m, p->Cc, 1, 0, params + p->tensors[c0.kernel_t].off, D2, 1, wst, ws + L.cbt, p->N * D2, D2,
+                                           B, D2, p->Cc, p->N, nullptr, 0, s);
+      } else
       rc = Gemm(1, B, p->N * D2, ceil32(p->N * D2)).seg(m, p->Cc, p->Cc, 0, fragbase + p->frag_condF).run(ws + L.cbt, p->N * D2, s);
       if (rc) return rc;
       rc = wn_launch_cond_scatter(ws + L.cbt, params, p->tensors[c0.bias_t].off, bst, B, p->N, D2, ws + L.cb, s);
@@ -2378,6 +2399,15 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       rc = wn_launch_cond_gather(ws + L.bslab, p->nparams, L.bsplits, p->tensors[b0.dil.back().bias_t].off, dst, B, p->N, D2,
                                  ws + L.cbt, s);
       if (rc) return rc;
+      if (cond_small(p) && (int64_t)p->N * B * p->Cc <= L.slab_floats) {
+        // g_m = sum_z dcb_z W_c(z)^T: one product per block into the (idle) slab, then their sum
+        rc = wn_launch_sgemm_small_batched(ws + L.cbt, p->N * D2, 1, D2, params + p->tensors[b0.conv_cond.kernel_t].off, 1, D2, wst,
+                                           slab, p->Cc, (int64_t)B * p->Cc, B, p->Cc, D2, p->N, nullptr, 0, s);
+        if (rc) return rc;
+        WnVecSumArgs v;
+        v.base = slab; v.off0 = 0; v.stride = (int64_t)B * p->Cc; v.count = p->N; v.len = B * p->Cc; v.out = ws + L.g_m0;
+        rc = wn_launch_vecsum(v, s);
+      } else
       rc = Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.cbt, p->N * D2, p->N * D2, 0, fragbase + p->frag_condB).run(ws + L.g_m0, p->Cc, s);
       if (rc) return rc;
       rc = wn_launch_cond_wgrad(mlast, ws + L.cbt, B, p->Cc, p->N, D2, grads, p->tensors[b0.conv_cond.kernel_t].off, wst,
@@ -2478,6 +2508,23 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       // pre-activation gradient g_pre = g * act'(M[j])  (tiny: B x width)
       rc = wn_launch_dact_mul(gm_cur, ws + L.M[j], gm_other, (int64_t)B * c.cout, p->c.mapping_activation, s);
       if (rc) return rc;
+      if (cond_small(p)) {
+        // dW = yin^T g_pre (cin x cout, contraction over the B utterances), db = column sums of g_pre
+        rc = wn_launch_sgemm_small_batched(yin, 1, c.cin, 0, gm_other, c.cout, 1, 0, grads + p->tensors[c.kernel_t].off, c.cout, 0,
+                                           c.cin, c.cout, B, 1, nullptr, 0, s);
+        if (rc) return rc;
+        WnVecSumArgs v;
+        v.base = gm_other; v.off0 = 0; v.stride = c.cout; v.count = B; v.len = c.cout; v.out = grads + p->tensors[c.bias_t].off;
+        rc = wn_launch_vecsum(v, s);
+        if (rc) return rc;
+        if (j > 0) {          // g_in = g_pre W^T
+          float* dst = const_cast<float*>(gm_cur);
+          rc = wn_launch_sgemm_small_batched(gm_other, c.cout, 1, 0, params + p->tensors[c.kernel_t].off, 1, c.cout, 0, dst, c.cin, 0,
+                                             B, c.cin, c.cout, 1, nullptr, 0, s);
+          if (rc) return rc;
+        }
+        continue;
+      }
       rc = wgrad(yin, c.cin, c.cin, 0, gm_other, c.cout, c.cout, 1, B, grads + p->tensors[c.kernel_t].off,
                  grads + p->tensors[c.bias_t].off, nullptr, slab, s);
       if (rc) return rc;
