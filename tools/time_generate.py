@@ -8,7 +8,13 @@ import bench
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device('cuda', 0)
-m = WaveNet(**bench.CFG2, device=dev)
+# second argument 'cfg3': BASELINE configs[3] weights (128 residual channels, MoL-10) instead of configs[1]
+kw = bench.OTHER_CONFIGS['configs[3]'][0] if len(sys.argv) > 2 and sys.argv[2] == 'cfg3' else bench.CFG2
+m = WaveNet(**kw, device=dev)
+# further arguments: KEY VAL pairs of debug knobs (wavenets_amd/csrc/wn_error.cpp)
+from wavenets_amd import _lib
+for k_, v_ in zip(sys.argv[3::2], sys.argv[4::2]):
+  _lib.lib().wn_debug_set(int(k_), int(v_))
 w = (torch.rand(B, m.receptive_field, 1, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
 for name, queued, n, det in (('naive', False, 20, True), ('queued', True, 400, True), ('queued, stochastic draws', True, 400, False)):
   m.generate(3, sample=w, use_queues=queued, deterministic=det)

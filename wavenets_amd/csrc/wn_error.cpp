@@ -51,6 +51,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   31  = 1: the folded skip contraction on wn_gemm_rows16_kernel (no wn_gemm_planes16s_kernel)
 //   32  = 1: the folded skip path's small weight-space products on the 64 x 64-tile kernel (no wn_sgemm_small32_kernel)
 //   33  = 1: the conditioning path (mapping Dense stack, conditioning convs) as rows-GEMM launches (no small-product kernel)
+//   34  = 1: queued generation of 128-channel blocks on the streamed forward kernel, one launch per block;
+//       = 2: on wn_gen_block128_kernel, one launch per block (default: wn_gen_chain128_kernel, all blocks in one launch)
 // thread-local: a caller that switches kernel variants (the range guard's exact-fp32 retry, tools/ A/B runs, tests)
 // affects the launches of its own thread only
 static thread_local int g_wn_debug[64] = {0};

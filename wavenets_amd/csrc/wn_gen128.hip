@@ -1,0 +1,392 @@
+// One residual block of one queued-generation time step for R = D = 128 (gfx950): rows = utterances (<= 32 per tile).
+// Reference: WaveNetLayer.generate, src/layers.py:226-290 -- the step of WaveNetLayer.call on one time sample.
+//
+// The training-forward kernel of these blocks (wn_layer16s.hip) STREAMS its 320 KiB of weight images through LDS two
+// 16 KiB chunks ahead.  With 32 time steps per wave that hides the stream; with one row per utterance it is ten dependent
+// L2 round trips per block (25-30 us a block, 0.96 ms a step for 30 blocks = 1.0 k samples/s per utterance).  Here one
+// workgroup of 8 waves takes the block; wave w owns output row tile w of the gated conv (32 of the 256 channels of u)
+// and requests ALL 16 k-steps of its weight fragments, hi and lo, straight into registers before anything else (128
+// VGPRs, one round trip for the whole conv), waves 0..3 also their 8 k-steps of the 1x1.  The operand rows (two taps x
+// 128 channels of at most 32 utterances) are staged once in LDS in B-fragment order.  The gate pairs tiles j and j + 4
+// through LDS, the 1x1 reads the z tiles back as they stand.
+//
+// Bit for bit the arithmetic of wn_layer_fwd_s128_kernel (the sliding window's kernel) per output element: accumulators
+// start at the bias (+ conditioning bias), k-steps ascending with lo*hi, hi*lo, hi*hi each, the same gate functions, the
+// 1x1 the same way from the z tiles, x_out = o + residual in fp32.  tests: queued == sliding window.
+#include "wn_stream.h"
+
+using namespace wn_stream;
+
+namespace {
+
+__device__ __forceinline__ h8 ldg_h8(const void* p) { return *(const __attribute__((address_space(1))) h8*)(p); }
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const __attribute__((address_space(1))) f32x4*)(p); }
+
+}  // namespace
+
+// a.xt[0], a.xt[1]: the two taps' rows [B][128]; a.x = residual source when a.res is null (the newest tap); T == 1
+__global__ __launch_bounds__(512, 2) void wn_gen_block128_kernel(WnLayerFwdArgs a) {
+  constexpr int R = 128, D = 128, NK1 = 16, NK2 = 8;
+  // LDS: operand fragments of the conv [16 k-steps][2][64 lanes] x 16 B | gate tiles [4][16][64] floats | z tiles [4][16][64]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NK1 * 2048 + 2 * 4 * 16 * 64 * 4];
+  f32x4* xs = reinterpret_cast<f32x4*>(smem);
+  float* gs = reinterpret_cast<float*>(smem + NK1 * 2048);
+  float* zs = gs + 4 * 16 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = lane & 31, h = lane >> 5;
+  const int row = blockIdx.x * 32 + tl;                 // utterance of this lane's column
+  const bool rok = row < a.B;
+
+  // ---- every weight fragment of this wave, requested at once ----
+  h8 wd[NK1][2];
+  {
+    const char* base = reinterpret_cast<const char*>(a.frag_d) + (int64_t)wave * 2048 + lane * 16;   // k-step c: + c * 16384
+#pragma unroll
+    for (int c = 0; c < NK1; ++c) {
+      wd[c][0] = ldg_h8(base + c * 16384);              // hi
+      wd[c][1] = ldg_h8(base + c * 16384 + 1024);       // lo
+    }
+  }
+  h8 wr[NK2][2];
+  if (wave < 4) {
+    const char* base = reinterpret_cast<const char*>(a.frag_r) + (int64_t)wave * 2048 + lane * 16;   // k-step ks: + ks * 8192
+#pragma unroll
+    for (int ks = 0; ks < NK2; ++ks) {
+      wr[ks][0] = ldg_h8(base + ks * 8192);
+      wr[ks][1] = ldg_h8(base + ks * 8192 + 1024);
+    }
+  }
+  // ---- operand rows -> LDS in B-fragment order: piece (c, q, lane) = channels 16 kk + 8 q + 4 h .. + 3 of row tl, tap c / 8 ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + 512 * i;                        // 2048 pieces of 16 bytes
+    const int c = e >> 7, q = (e >> 6) & 1, l = e & 63;
+    const int r2 = blockIdx.x * 32 + (l & 31);
+    const float* src = (c < 8 ? a.xt[0] : a.xt[1]) + (int64_t)(r2 < a.B ? r2 : 0) * R + 16 * (c & 7) + 8 * q + 4 * (l >> 5);
+    f32x4 v = ldg4(src);
+    if (r2 >= a.B) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    xs[e] = v;
+  }
+  // ---- accumulators start at the bias (+ per-utterance conditioning bias) ----
+  f32x16 u;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const f32x4 bv = ldg4(a.bias_d + 32 * wave + 8 * rq + 4 * h);
+    u[4 * rq + 0] = bv.x; u[4 * rq + 1] = bv.y; u[4 * rq + 2] = bv.z; u[4 * rq + 3] = bv.w;
+  }
+  if (a.cb) {
+    const float* cbp = a.cb + (int64_t)(rok ? row : 0) * 2 * D + 4 * h + 32 * wave;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      // (wn_layer_fwd_s128_kernel adds the conditioning bias of the tile's utterance: rows of a tile are one utterance
+      // there, one utterance per column here)
+      const f32x4 cv = ldg4(cbp + 8 * rq);
+      u[4 * rq + 0] += cv.x; u[4 * rq + 1] += cv.y; u[4 * rq + 2] += cv.z; u[4 * rq + 3] += cv.w;
+    }
+  }
+  __syncthreads();
+  // ---- gated conv: 16 k-steps ----
+#pragma unroll
+  for (int c = 0; c < NK1; ++c) {
+    const f32x4 q0 = xs[(c * 2 + 0) * 64 + lane], q1 = xs[(c * 2 + 1) * 64 + lane];
+    h8 bh, bl;
+    split8(q0, q1, bh, bl);
+    u = mfma16(wd[c][1], bh, u);
+    u = mfma16(wd[c][0], bl, u);
+    u = mfma16(wd[c][0], bh, u);
+  }
+  // ---- gate: tiles 4..7 hold the gate channels of tiles 0..3 ----
+  if (wave >= 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gs[((wave - 4) * 16 + r) * 64 + lane] = wn_sigmoid_fast(u[r]);
+  }
+  __syncthreads();
+  float wmax = 0.f;
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sg = gs[(wave * 16 + r) * 64 + lane];
+      u[r] = wn_tanh_fast(u[r]) * sg;
+      zs[(wave * 16 + r) * 64 + lane] = u[r];
+    }
+    if (a.z_out && rok) {
+      float* zp = a.z_out + (int64_t)row * a.ldz + 32 * wave + 4 * h;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 o;
+        o.x = u[4 * rq + 0]; o.y = u[4 * rq + 1]; o.z = u[4 * rq + 2]; o.w = u[4 * rq + 3];
+        *reinterpret_cast<f32x4*>(zp + 8 * rq) = o;
+      }
+    }
+  }
+  // the 1x1's bias and the residual rows are requested before the barrier (the conv's weight registers are free now):
+  // they arrive while the z tiles are exchanged
+  f32x4 bv4[4], rv4[4];
+  if (wave < 4) {
+    const float* rp = (a.res ? a.res : a.x) + (int64_t)(rok ? row : 0) * R + 32 * wave + 4 * h;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      bv4[rq] = ldg4(a.bias_r + 32 * wave + 8 * rq + 4 * h);
+      rv4[rq] = a.residual ? ldg4(rp + 8 * rq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  if (wave < 4) {
+    // ---- 1x1: 8 k-steps, B operand = the z tiles as they stand ----
+    f32x16 o;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 bv = bv4[rq];
+      o[4 * rq + 0] = bv.x; o[4 * rq + 1] = bv.y; o[4 * rq + 2] = bv.z; o[4 * rq + 3] = bv.w;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK2; ++ks) {
+      const int jz = ks >> 1, r0 = 8 * (ks & 1);
+      f32x4 q0, q1;
+      q0.x = zs[(jz * 16 + r0 + 0) * 64 + lane]; q0.y = zs[(jz * 16 + r0 + 1) * 64 + lane];
+      q0.z = zs[(jz * 16 + r0 + 2) * 64 + lane]; q0.w = zs[(jz * 16 + r0 + 3) * 64 + lane];
+      q1.x = zs[(jz * 16 + r0 + 4) * 64 + lane]; q1.y = zs[(jz * 16 + r0 + 5) * 64 + lane];
+      q1.z = zs[(jz * 16 + r0 + 6) * 64 + lane]; q1.w = zs[(jz * 16 + r0 + 7) * 64 + lane];
+      h8 bh, bl;
+      split8(q0, q1, bh, bl);
+      o = mfma16(wr[ks][1], bh, o);
+      o = mfma16(wr[ks][0], bl, o);
+      o = mfma16(wr[ks][0], bh, o);
+    }
+    // ---- residual, range guard, x_out ----
+    if (rok) {
+      float* op = a.x_out + (int64_t)row * R + 32 * wave + 4 * h;
+      float* pp = a.o_out ? a.o_out + (int64_t)row * R + 32 * wave + 4 * h : nullptr;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 ov;
+        ov.x = o[4 * rq + 0]; ov.y = o[4 * rq + 1]; ov.z = o[4 * rq + 2]; ov.w = o[4 * rq + 3];
+        if (pp) *reinterpret_cast<f32x4*>(pp + 8 * rq) = ov;
+        wmax = wn_absmax_acc(wmax, ov.x, ov.y, ov.z, ov.w);
+        if (a.residual) {
+          const f32x4 rv = rv4[rq];
+          wmax = wn_absmax_acc(wmax, rv.x, rv.y, rv.z, rv.w);
+          ov.x += rv.x; ov.y += rv.y; ov.z += rv.z; ov.w += rv.w;
+        }
+        *reinterpret_cast<f32x4*>(op + 8 * rq) = ov;
+      }
+    }
+    if (a.absmax_out) {
+      wmax = wn_wave_absmax_bits(wmax);
+      if (lane == 0) wn_absmax_publish_any(a.absmax_out, wmax);
+    }
+  }
+}
+
+// All residual blocks of one queued-generation step in ONE launch (R = D = 128, kernel size 2, depth 1): the loop over
+// blocks of the kernel above inside the workgroup.  Block b's output rows stay in LDS as the newest tap of block b + 1 (a
+// D-layout tile IS the next conv's B-operand piece of the same lane) and as its residual; only the older tap comes from
+// the block's ring.  Per block: one round trip for the weight fragments, 48 + 24 products, three barriers.
+__global__ __launch_bounds__(512, 2) void wn_gen_chain128_kernel(WnGen128Args a) {
+  constexpr int R = 128, D = 128, NK1 = 16, NK2 = 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NK1 * 2048 + 2 * 4 * 16 * 64 * 4];
+  f32x4* xs = reinterpret_cast<f32x4*>(smem);
+  float* gs = reinterpret_cast<float*>(smem + NK1 * 2048);
+  float* zs = gs + 4 * 16 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = lane & 31, h = lane >> 5;
+  const int row = blockIdx.x * 32 + tl;
+  const bool rok = row < a.B;
+  float wmax = 0.f;
+  // folded skip contraction (a.skip_tiles == 4: 128 columns): waves 4..7 own one column tile each and carry its accumulator
+  // through all blocks -- k ascending over (block, k-step) from zero, as wn_gemm_planes16s_kernel runs it
+  const bool skip_on = a.skip_w16_off >= 0;
+  f32x16 sacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+  for (int b = 0; b < a.nblocks; ++b) {
+    const WnGenBlock g = a.blocks[b];
+    const float* ring = a.ws + g.ring_off;
+    const float* xold = ring + (int64_t)((a.tau - g.dilation) % g.nslots) * a.B * R;
+    const float* xnew = ring + (int64_t)(a.tau % g.nslots) * a.B * R;
+    h8 wd[NK1][2];
+    {
+      const char* base = reinterpret_cast<const char*>(a.ws + g.w16d_off) + (int64_t)wave * 2048 + lane * 16;
+#pragma unroll
+      for (int c = 0; c < NK1; ++c) {
+        wd[c][0] = ldg_h8(base + c * 16384);
+        wd[c][1] = ldg_h8(base + c * 16384 + 1024);
+      }
+    }
+    h8 wr[NK2][2];                                     // waves 0..3: the 1x1's fragments; 4..7: the skip contraction's
+    f32x4 bv4[4];
+    if (wave < 4 || skip_on) {
+      const char* base = wave < 4 ? reinterpret_cast<const char*>(a.ws + g.w16r_off) + (int64_t)wave * 2048 + lane * 16
+                                  : reinterpret_cast<const char*>(a.ws + a.skip_w16_off) + (int64_t)b * (NK2 * 8192) +
+                                        (int64_t)(wave - 4) * 2048 + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < NK2; ++ks) {
+        wr[ks][0] = ldg_h8(base + ks * 8192);
+        wr[ks][1] = ldg_h8(base + ks * 8192 + 1024);
+      }
+    }
+    // operand rows: the older tap from the ring (block 0: the newest tap too, written by the input conv's launch)
+    const int npieces = b == 0 ? 2048 : 1024;
+    for (int e = tid; e < npieces; e += 512) {
+      const int c = e >> 7, q = (e >> 6) & 1, l = e & 63;
+      const int r2 = blockIdx.x * 32 + (l & 31);
+      const float* src = (c < 8 ? xold : xnew) + (int64_t)(r2 < a.B ? r2 : 0) * R + 16 * (c & 7) + 8 * q + 4 * (l >> 5);
+      f32x4 v = ldg4(src);
+      if (r2 >= a.B) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      xs[e] = v;
+    }
+    f32x16 u;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 bv = ldg4(a.params + g.bias_d_off + 32 * wave + 8 * rq + 4 * h);
+      u[4 * rq + 0] = bv.x; u[4 * rq + 1] = bv.y; u[4 * rq + 2] = bv.z; u[4 * rq + 3] = bv.w;
+    }
+    if (g.cb_off >= 0) {
+      const float* cbp = a.ws + g.cb_off + (int64_t)(rok ? row : 0) * 2 * D + 4 * h + 32 * wave;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 cv = ldg4(cbp + 8 * rq);
+        u[4 * rq + 0] += cv.x; u[4 * rq + 1] += cv.y; u[4 * rq + 2] += cv.z; u[4 * rq + 3] += cv.w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NK1; ++c) {
+      const f32x4 q0 = xs[(c * 2 + 0) * 64 + lane], q1 = xs[(c * 2 + 1) * 64 + lane];
+      h8 bh, bl;
+      split8(q0, q1, bh, bl);
+      u = mfma16(wd[c][1], bh, u);
+      u = mfma16(wd[c][0], bl, u);
+      u = mfma16(wd[c][0], bh, u);
+    }
+    if (wave >= 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gs[((wave - 4) * 16 + r) * 64 + lane] = wn_sigmoid_fast(u[r]);
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sg = gs[(wave * 16 + r) * 64 + lane];
+        u[r] = wn_tanh_fast(u[r]) * sg;
+        zs[(wave * 16 + r) * 64 + lane] = u[r];
+      }
+      if (rok) {
+        float* zp = a.ws + a.zrow_off + ((int64_t)b * a.B + row) * D + 32 * wave + 4 * h;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          f32x4 o;
+          o.x = u[4 * rq + 0]; o.y = u[4 * rq + 1]; o.z = u[4 * rq + 2]; o.w = u[4 * rq + 3];
+          *reinterpret_cast<f32x4*>(zp + 8 * rq) = o;
+        }
+      }
+      // (requested here, when the conv's weight registers are free: in flight across the barrier)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) bv4[rq] = ldg4(a.params + g.bias_r_off + 32 * wave + 8 * rq + 4 * h);
+    }
+    __syncthreads();
+    if (wave < 4) {
+      f32x16 o;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 bv = bv4[rq];
+        o[4 * rq + 0] = bv.x; o[4 * rq + 1] = bv.y; o[4 * rq + 2] = bv.z; o[4 * rq + 3] = bv.w;
+      }
+#pragma unroll
+      for (int ks = 0; ks < NK2; ++ks) {
+        const int jz = ks >> 1, r0 = 8 * (ks & 1);
+        f32x4 q0, q1;
+        q0.x = zs[(jz * 16 + r0 + 0) * 64 + lane]; q0.y = zs[(jz * 16 + r0 + 1) * 64 + lane];
+        q0.z = zs[(jz * 16 + r0 + 2) * 64 + lane]; q0.w = zs[(jz * 16 + r0 + 3) * 64 + lane];
+        q1.x = zs[(jz * 16 + r0 + 4) * 64 + lane]; q1.y = zs[(jz * 16 + r0 + 5) * 64 + lane];
+        q1.z = zs[(jz * 16 + r0 + 6) * 64 + lane]; q1.w = zs[(jz * 16 + r0 + 7) * 64 + lane];
+        h8 bh, bl;
+        split8(q0, q1, bh, bl);
+        o = mfma16(wr[ks][1], bh, o);
+        o = mfma16(wr[ks][0], bl, o);
+        o = mfma16(wr[ks][0], bh, o);
+      }
+      // residual = this lane's own pieces of the newest tap in LDS; x_out goes back into the same pieces (the next block's
+      // newest tap) and to the next block's ring slot
+      float* dst = nullptr;
+      if (b + 1 < a.nblocks) {
+        const WnGenBlock gn = a.blocks[b + 1];
+        dst = a.ws + gn.ring_off + (int64_t)(a.tau % gn.nslots) * a.B * R;
+      } else if (a.hrow_off >= 0) {
+        dst = a.ws + a.hrow_off;
+      }
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 ov;
+        ov.x = o[4 * rq + 0]; ov.y = o[4 * rq + 1]; ov.z = o[4 * rq + 2]; ov.w = o[4 * rq + 3];
+        const int piece = ((8 + 2 * wave + (rq >> 1)) * 2 + (rq & 1)) * 64 + lane;
+        if (rok) wmax = wn_absmax_acc(wmax, ov.x, ov.y, ov.z, ov.w);
+        if (a.residual) {
+          const f32x4 rv = xs[piece];
+          if (rok) wmax = wn_absmax_acc(wmax, rv.x, rv.y, rv.z, rv.w);
+          ov.x += rv.x; ov.y += rv.y; ov.z += rv.z; ov.w += rv.w;
+        }
+        xs[piece] = rok ? ov : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (dst && rok) *reinterpret_cast<f32x4*>(dst + (int64_t)row * R + 32 * wave + 8 * rq + 4 * h) = ov;
+      }
+    }
+    else if (skip_on) {
+#pragma unroll
+      for (int ks = 0; ks < NK2; ++ks) {
+        const int jz = ks >> 1, r0 = 8 * (ks & 1);
+        f32x4 q0, q1;
+        q0.x = zs[(jz * 16 + r0 + 0) * 64 + lane]; q0.y = zs[(jz * 16 + r0 + 1) * 64 + lane];
+        q0.z = zs[(jz * 16 + r0 + 2) * 64 + lane]; q0.w = zs[(jz * 16 + r0 + 3) * 64 + lane];
+        q1.x = zs[(jz * 16 + r0 + 4) * 64 + lane]; q1.y = zs[(jz * 16 + r0 + 5) * 64 + lane];
+        q1.z = zs[(jz * 16 + r0 + 6) * 64 + lane]; q1.w = zs[(jz * 16 + r0 + 7) * 64 + lane];
+        h8 bh, bl;
+        split8(q0, q1, bh, bl);
+        sacc = mfma16(wr[ks][1], bh, sacc);
+        sacc = mfma16(wr[ks][0], bl, sacc);
+        sacc = mfma16(wr[ks][0], bh, sacc);
+      }
+    }
+    // (the next iteration's barrier after staging orders these LDS writes before the conv reads them; zs is rewritten
+    // two barriers later)
+  }
+  if (skip_on && wave >= 4) {
+    // + bias, activation, range guard: the epilogue of wn_gemm_planes16s_kernel
+    const int j = wave - 4;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int n0 = 32 * j + 8 * rq + 4 * h;
+      const f32x4 bv = ldg4(a.ws + a.skip_bias_off + n0);
+      f32x4 v;
+      v.x = wn_act(sacc[4 * rq + 0] + bv.x, a.skip_act); v.y = wn_act(sacc[4 * rq + 1] + bv.y, a.skip_act);
+      v.z = wn_act(sacc[4 * rq + 2] + bv.z, a.skip_act); v.w = wn_act(sacc[4 * rq + 3] + bv.w, a.skip_act);
+      if (rok) {
+        wmax = wn_absmax_acc(wmax, v.x, v.y, v.z, v.w);
+        *reinterpret_cast<f32x4*>(a.ws + a.skiprow_off + (int64_t)row * 128 + n0) = v;
+      }
+    }
+  }
+  if (a.guard && (wave < 4 || skip_on)) {
+    wmax = wn_wave_absmax_bits(wmax);
+    if (lane == 0) wn_absmax_publish_any(a.guard, wmax);
+  }
+}
+
+int wn_launch_gen_chain128(const WnGen128Args& a, hipStream_t s) {
+  if (a.B <= 0 || a.nblocks <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_gen_chain128_kernel, dim3((unsigned)((a.B + 31) / 32)), dim3(512), 0, s, a);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
+int wn_gen_block128_supported(int R, int D, int KS) { return R == 128 && D == 128 && KS == 2; }
+
+int wn_launch_gen_block128(const WnLayerFwdArgs& a, hipStream_t s) {
+  if (!wn_gen_block128_supported(a.R, a.D, a.KS) || a.T != 1 || !a.xt[0] || !a.xt[1] || a.ag_out || (a.z_out && a.ldz % 4 != 0)) {
+    wn_set_error("gen_block128: unsupported call (R=%d D=%d KS=%d T=%d)", a.R, a.D, a.KS, a.T);
+    return WN_E_UNSUPPORTED;
+  }
+  if (a.B <= 0) return WN_OK;
+  hipLaunchKernelGGL(wn_gen_block128_kernel, dim3((unsigned)((a.B + 31) / 32)), dim3(512), 0, s, a);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}

@@ -200,6 +200,10 @@ size_t wn_frag16_floats(int I, int KK);
 int wn_layer_fwd_s128_supported(int R, int D, int KS);
 int wn_launch_layer_fwd_s128(const WnLayerFwdArgs& a, hipStream_t s);
 int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s);
+// one queued-generation step of a 128-channel block, rows = utterances (wn_gen128.hip): same arguments as the streamed
+// forward with T == 1 and both taps given as xt[0], xt[1]
+int wn_gen_block128_supported(int R, int D, int KS);
+int wn_launch_gen_block128(const WnLayerFwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fused generation step (wn_gen.hip)
 struct WnGenBlock {
@@ -235,6 +239,22 @@ struct WnGenStepArgs {
   float* guard;                    // range guard of the generate call: running max-abs of the residual stream and of the
                                    // folded skip sum (the split-precision casts need |.| < 65504), or null
 };
+// every block of one queued-generation step for 128-channel blocks in one launch (wn_gen128.hip); the table's w16d_off is
+// the natural-order image of the gated conv (BlockInfo::f16nat)
+struct WnGen128Args {
+  const float* params;
+  float* ws;
+  const WnGenBlock* blocks;        // device table
+  int64_t zrow_off;                // [N][B][D] gated activations of this step
+  int64_t hrow_off;                // [B][R] last block output (use_skip False) or < 0
+  int64_t tau;
+  int32_t B, nblocks, residual;
+  float* guard;                    // range guard of the generate call or null
+  // folded skip contraction with 128 columns inside the chain (waves 4..7), or skip_w16_off < 0
+  int64_t skip_w16_off, skip_bias_off, skiprow_off;
+  int32_t skip_act;
+};
+int wn_launch_gen_chain128(const WnGen128Args& a, hipStream_t s);
 // queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)
 struct WnEmit { float* out; int length; int step; float* xin_slot; };
 // the head of a generation step in one launch (wn_gen.hip)

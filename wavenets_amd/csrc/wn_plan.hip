@@ -126,7 +126,8 @@ struct wn_plan {
   WnGenBlock gen_blk0[3]{};
   int64_t gen_bias_stride = 0;
   int train_phases = 3;   // wn_plan_set_train_phases: bit 0 forward + loss (+ step sample), bit 1 backward + weight gradients
-  int gen_B = 0;      // dW_s handled by the dedicated skip weight-gradient kernel, not by jobs
+  int gen_B = 0;
+  bool gen_chain128 = false;   // the cached generation table carries the 128-channel chain's images
   // optional HIP-event timing of the fused block-forward launches (bench.py roofline leg)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   std::vector<int> prof_cnt;         // launches between the events of pair i
@@ -696,6 +697,10 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     a.xt[0] = f.xt[0]; a.xt[1] = f.xt[1]; a.xt[2] = nullptr;
     a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
     a.absmax_out = f.fwd_absmax;
+    // one row per utterance (a queued-generation step): the whole block in one workgroup with every weight fragment
+    // requested up front instead of the streamed pipeline (wn_gen128.hip, same arithmetic; knob 34 = 1: the streamed kernel)
+    if (k.T == 1 && f.xt[0] && f.xt[1] && !f.AG && wn_debug_get(34) != 1 && wn_gen_block128_supported(k.R, k.D, k.KS))   // (34 = 2 too)
+      return wn_launch_gen_block128(a, s);
     return wn_launch_layer_fwd_s128(a, s);
   }
   // the same blocks as [gated conv + gate] -> [1x1 + residual], two split-precision contractions, ahead of the exact-fp32
@@ -2774,13 +2779,21 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   const size_t first_final = gfold ? 1 : 0;
   const bool skip_in_chain = fused_step && p->c.use_skip && skip_img >= 0 && wn_gen_skip_fusable(skipw) &&
                              wn_debug_get(6) != 2;   // knob 6 = 2: skip contraction as its own launch
-  if (fused_step && (!p->d_gen || p->gen_B != B)) {
+  // 128-channel blocks: every block of a step in one launch of wn_gen_chain128_kernel (knob 34 = 1: the streamed forward
+  // kernel per block, = 2: wn_gen_block128_kernel per block)
+  const bool chain128 = !fused_step && p->LPB == 1 && p->Dp == p->D && wn_gen_block128_supported(p->R, p->D, p->KS) &&
+                        !p->blocks.empty() && p->blocks[0].f16nat >= 0 && p->blocks[0].conv1.frag16 >= 0 && wn_debug_get(1) != 1 &&
+                        wn_debug_get(11) == 0 && wn_debug_get(34) == 0 && fits32;
+  // (its folded skip contraction -- 128 columns -- rides in the same launch; knob 6 = 2: its own launch)
+  const bool skip_in_chain128 = chain128 && gfold && p->c.use_skip && skipw == 128 && skip_img >= 0 && wn_debug_get(6) != 2;
+  if ((fused_step || chain128) && (!p->d_gen || p->gen_B != B || p->gen_chain128 != chain128)) {
+    p->gen_chain128 = chain128;
     std::vector<WnGenBlock> tab(p->N);
     for (int b = 0; b < p->N; ++b) {
       const BlockInfo& bi = p->blocks[b];
       WnGenBlock& g = tab[b];
       g.ring_off = G.ring[b];
-      g.w16d_off = G.prime + L.frag + bi.dil.back().frag16;
+      g.w16d_off = G.prime + L.frag + (chain128 ? bi.f16nat : bi.dil.back().frag16);
       g.w16r_off = G.prime + L.frag + bi.conv1.frag16;
       g.bias_d_off = p->tensors[bi.dil.back().bias_t].off;
       g.bias_r_off = p->tensors[bi.conv1.bias_t].off;
@@ -2844,7 +2857,21 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       rc = g.bias(params + p->tensors[p->causal.bias_t].off).run(R.h[0] + (int64_t)(tau % R.nslots[0]) * B * p->R, p->R, s);
       if (rc) return rc;
     }
-    for (int b = 0; b < p->N; ++b) {
+    if (chain128) {
+      WnGen128Args ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.params = params; ca.ws = workspace; ca.blocks = p->d_gen; ca.zrow_off = G.Zrow;
+      ca.hrow_off = p->c.use_skip ? -1 : G.hrow0; ca.tau = tau; ca.B = B; ca.nblocks = p->N; ca.residual = p->c.use_residual;
+      ca.guard = gguard;
+      ca.skip_w16_off = -1;
+      if (skip_in_chain128) {
+        ca.skip_w16_off = G.prime + L.frag + skip_img; ca.skip_bias_off = G.prime + L.bfold; ca.skiprow_off = G.skiprow;
+        ca.skip_act = p->c.activation;
+      }
+      rc = wn_launch_gen_chain128(ca, s);
+      if (rc) return rc;
+    }
+    for (int b = 0; b < p->N && !chain128; ++b) {
       BlockPtrs k = block_ptrs(p, b, params, fragbase, B, 1);
       if (p->c.cond_inputs > 0) k.cb = pws + L.cb + (int64_t)b * B * 2 * p->D;
       const int d = p->blocks[b].dil.back().dil;
@@ -2885,7 +2912,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     }
     }
     const float* hin;
-    if (skip_in_chain) {
+    if (skip_in_chain || skip_in_chain128) {
       hin = workspace + G.skiprow;
     } else if (p->c.use_skip) {
       // utterances are the ROWS of these contractions (no time shift, no per-utterance bias here)
