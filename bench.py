@@ -113,6 +113,21 @@ def generation_leg(dev, B: int = 8, n: int = 1000):
       ts.append(best)
     per = (ts[1] - ts[0]) / (steps - steps // 4)
     res[name] = {'ms_per_sample_step': per * 1e3, 'samples_per_s_per_utterance': 1.0 / per, 'samples_per_s_aggregate': B / per}
+  del m
+  # configs[3] weights (128 residual channels, mixture-of-logistics draws): the queued sampler's other kernel family
+  m3 = WaveNet(**OTHER_CONFIGS['configs[3]'][0], device=dev, seed=0)
+  w3 = (torch.rand(B, m3.receptive_field, 1, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+  ts = []
+  for k in (100, 400):
+    m3.generate(k, sample=w3, use_queues=True, deterministic=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m3.generate(k, sample=w3, use_queues=True, deterministic=False)
+    torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+  per = (ts[1] - ts[0]) / 300
+  res['configs3_queued_stochastic'] = {'ms_per_sample_step': per * 1e3, 'samples_per_s_per_utterance': 1.0 / per,
+                                       'samples_per_s_aggregate': B / per}
   return res
 
 

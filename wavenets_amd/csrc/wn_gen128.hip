@@ -230,8 +230,24 @@ __global__ __launch_bounds__(512, 2) void wn_gen_chain128_kernel(WnGen128Args a)
     for (int e = tid; e < npieces; e += 512) {
       const int c = e >> 7, q = (e >> 6) & 1, l = e & 63;
       const int r2 = blockIdx.x * 32 + (l & 31);
-      const float* src = (c < 8 ? xold : xnew) + (int64_t)(r2 < a.B ? r2 : 0) * R + 16 * (c & 7) + 8 * q + 4 * (l >> 5);
-      f32x4 v = ldg4(src);
+      const int ch0 = 16 * (c & 7) + 8 * q + 4 * (l >> 5);
+      const float* src = (c < 8 ? xold : xnew) + (int64_t)(r2 < a.B ? r2 : 0) * R + ch0;
+      f32x4 v;
+      if (c >= 8 && a.xin) {
+        // block 0's newest tap = the input causal conv of this step (src/model.py:84-88,228), computed here with the
+        // arithmetic of wn_inconv_fwd_kernel (fma chain over the taps from zero, then + bias) and written to the ring
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int tap = 0; tap < 2; ++tap) {
+          const float xv = a.xin[(int64_t)((a.tau - (1 - tap)) % 2) * a.B + (r2 < a.B ? r2 : 0)];
+          const f32x4 wv = ldg4(a.causal_w + (int64_t)tap * R + ch0);
+          a0 = fmaf(wv.x, xv, a0); a1 = fmaf(wv.y, xv, a1); a2 = fmaf(wv.z, xv, a2); a3 = fmaf(wv.w, xv, a3);
+        }
+        const f32x4 bv = ldg4(a.causal_b + ch0);
+        v = f32x4{a0 + bv.x, a1 + bv.y, a2 + bv.z, a3 + bv.w};
+        if (r2 < a.B) *reinterpret_cast<f32x4*>(a.ws + g.ring_off + (int64_t)(a.tau % g.nslots) * a.B * R + (int64_t)r2 * R + ch0) = v;
+      } else {
+        v = ldg4(src);
+      }
       if (r2 >= a.B) v = f32x4{0.f, 0.f, 0.f, 0.f};
       xs[e] = v;
     }

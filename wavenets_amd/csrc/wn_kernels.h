@@ -253,6 +253,9 @@ struct WnGen128Args {
   // folded skip contraction with 128 columns inside the chain (waves 4..7), or skip_w16_off < 0
   int64_t skip_w16_off, skip_bias_off, skiprow_off;
   int32_t skip_act;
+  // input causal conv (kernel size 2, one input channel) inside the chain: raw sample ring [2][B], kernel (2, 1, R), bias;
+  // or xin null: block 0's ring slot was written by an earlier launch
+  const float* xin; const float* causal_w; const float* causal_b;
 };
 int wn_launch_gen_chain128(const WnGen128Args& a, hipStream_t s);
 // queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)

@@ -2848,8 +2848,9 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       rc = wn_launch_gen_blocks(ga, p->R, p->KS, (pre_in_head && step > 1) ? 2 : 3, s);
       if (rc) return rc;
     } else {
-    // input causal conv on [x[tau-(KS-1)], ..., x[tau]]  ->  block 0's ring slot tau
-    {
+    // input causal conv on [x[tau-(KS-1)], ..., x[tau]]  ->  block 0's ring slot tau  (128-channel chain: inside its launch)
+    const bool inconv_in_chain = chain128 && p->KS == 2 && wn_debug_get(26) != 1;
+    if (!inconv_in_chain) {
       Gemm g(B, 1, p->R, ceil32(p->R));
       for (int t = 0; t < p->KS; ++t)
         g.seg(R.xin + (int64_t)((tau - (p->KS - 1 - t)) % p->KS) * B, 1, 1, 0,
@@ -2863,6 +2864,9 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       ca.params = params; ca.ws = workspace; ca.blocks = p->d_gen; ca.zrow_off = G.Zrow;
       ca.hrow_off = p->c.use_skip ? -1 : G.hrow0; ca.tau = tau; ca.B = B; ca.nblocks = p->N; ca.residual = p->c.use_residual;
       ca.guard = gguard;
+      if (inconv_in_chain) {
+        ca.xin = R.xin; ca.causal_w = params + p->tensors[p->causal.kernel_t].off; ca.causal_b = params + p->tensors[p->causal.bias_t].off;
+      }
       ca.skip_w16_off = -1;
       if (skip_in_chain128) {
         ca.skip_w16_off = G.prime + L.frag + skip_img; ca.skip_bias_off = G.prime + L.bfold; ca.skiprow_off = G.skiprow;
