@@ -939,6 +939,21 @@ def test_categorical_loss_kernel_forms_agree_bitwise():
   assert res[0][1] is not None and torch.equal(res[0][1], res[1][1])
 
 
+def test_forward_guard_check_can_be_deferred():
+  """range_check = False skips the per-call host read of the forward range guard; the deferred check reads the same slot."""
+  kw = dict(MODEL_CASES['cat_r64'])
+  ocfg, params, model = make_pair(seed=2, **kw)
+  x, _ = _inputs(kw, 2, 257)
+  ref = model(x.to(dev()))
+  model.range_check = False
+  out = model(x.to(dev()))
+  assert torch.equal(ref, out) and model.range_tripped_last_forward() is False
+  with torch.no_grad():
+    model.flat_params.mul_(3.0e3)                      # drive the residual stream beyond the fp16 range
+  model(x.to(dev()))
+  assert model.range_tripped_last_forward() is True
+
+
 @pytest.mark.parametrize('name', ['cat_r64', 'cat_r32_f128'])
 def test_fold_weight_space_products_and_reductions_agree_bitwise(name):
   """The folded skip path's small weight-space products on the 32 x 32-tile kernel (one round trip per 128 k) and on the

@@ -136,6 +136,11 @@ class WaveNet(torch.nn.Module):
     # None = automatic: a single replica reads its step scalars back between forward and backward; data-parallel replicas
     # take them from the gradient bucket's tail after the ONE all-reduce of the step (no second collective per step)
     self.early_logs = None
+    # call() / logits() read the forward range guard back after every pass (one blocking device-to-host copy) and repeat
+    # the pass in exact fp32 when it tripped.  False skips the read -- for latency-critical inference on weights known to
+    # stay in range; range_tripped_last_forward() checks the same slot later.
+    self.range_check = True
+    self._last_fwd = None
     self._log_mirror, self._log_event = None, None
     self._drop_step = 0                   # training calls made so far (dropout mask counter; saved by io.save_weights)
     self._fused_step_sample = True        # train_step draws its metric sample inside the library
@@ -354,10 +359,19 @@ class WaveNet(torch.nn.Module):
                     _lib.ptr(out) if want_probs else None, None if want_probs else _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                     _lib.stream_ptr()))
     run()
-    if L.wn_debug_value(1) != 1 and self._range_tripped(ws, B, T, training):
+    self._last_fwd = (ws, B, T, training)
+    if self.range_check and L.wn_debug_value(1) != 1 and self._range_tripped(ws, B, T, training):
       with self.exact_fp32():
         run()
     return out
+
+  def range_tripped_last_forward(self) -> bool:
+    """Deferred form of the guard check of call() / logits() (range_check = False): did the last forward pass leave the
+    range of the split-precision kernels?  (Repeat it inside `with model.exact_fp32():` if so.)"""
+    if self._last_fwd is None:
+      return False
+    ws, B, T, training = self._last_fwd
+    return bool(self._range_tripped(ws, B, T, training))
 
   def forward(self, inputs, training=False):
     return self.call(inputs, training=training)
