@@ -174,12 +174,16 @@ def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmu
       data = (x, torch.nn.functional.one_hot(spk, n_cond).float().to(dev))
     for _ in range(warmup):
       logs = m.train_step(data)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-      logs = m.train_step(data)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    # three blocks of `steps` steps, the median block reported (one block once came out 40 % slow on a shared host)
+    blocks_ms = []
+    for _ in range(3):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(steps):
+        logs = m.train_step(data)
+      torch.cuda.synchronize()
+      blocks_ms.append((time.perf_counter() - t0) / steps * 1e3)
+    dt = sorted(blocks_ms)[1] * 1e-3
     nblk = kw['blocks']
     nconv = nblk * kw.get('layers_per_block', 1)
     _, avg_ms, n_s, stack_ms, prep_ms = stack_profile(m, data, 5, nblk)
@@ -188,6 +192,7 @@ def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmu
     stack_bytes = nblk * 4.0 * B * T * (2 * R + S_eff)
     t_stack = stack_ms + prep_ms
     res[name] = {'workload': desc, 'kernel_families': m.kernel_report(), 'ms_per_step': dt * 1e3, 'samples_per_s': B * T / dt, 'steps': steps,
+                 'ms_per_step_blocks': blocks_ms,
                  'final_loss': logs['loss'],
                  'stack_fwd': {'t_stack_fwd_ms': t_stack, 't_fold_prep_ms': prep_ms, 'passes_timed': n_s,
                                'algorithmic_bytes': stack_bytes,
