@@ -13,7 +13,8 @@
 //   * a wave owns RT = 2 row tiles (64 time steps): every weight fragment read from LDS feeds two products, and the image
 //     is streamed from L2 once per 256 rows instead of once per 128 (the old kernel's variant of this spilled);
 //   * every request is an inline-assembly LDS-DMA from a scalar base (wn_stream.h), the only waits are counted vmcnt.
-// Measured at configs[1] (K = 1920): 294 -> see DESIGN.md section 9; configs[3] (K = 3840): 0.78 ms -> ibid.
+// Measured: configs[1] (K = 1920) 294 -> 270 us, configs[3] (K = 3840) 0.73 -> 0.71 ms: the pipeline was not what held this
+// contraction back (two k-steps of operands per wave in flight are right at bandwidth x latency).
 #include "wn_stream.h"
 
 using namespace wn_stream;
