@@ -1051,6 +1051,34 @@ def test_queued_generation_ring_wraparound():
   assert torch.equal(naive, queued)
 
 
+@pytest.mark.parametrize('B,cond', [(3, False), (40, False), (5, True)])
+def test_queued_generation_128_channel_chain(B, cond):
+  """128-channel blocks: every block of a step, the input conv and the folded skip contraction in one launch
+  (wn_gen_chain128_kernel) -- one and two utterance tiles, rings that wrap, with and without global conditioning -- and
+  the per-block launch forms (knob 34 = 2: wn_gen_block128_kernel, = 1: the streamed forward kernel) draw the sliding
+  window's samples."""
+  from wavenets_amd import _lib
+  kw = dict(blocks=5, channels=128, skip_channels=256, dilation_bound=16, final_layers_channels=[128, 64],
+            activation='leaky_relu', bits=8)
+  if cond:
+    kw.update(conditioning='global', mapping_layers=[8, 16], mapping_activation='leaky_relu', cond_inputs=7)
+  ocfg, params, model = make_pair(seed=17, bias_range=0.3, **kw)
+  w = O.synthetic_waveform(B, model.receptive_field, seed=3).to(dev())
+  c = torch.rand(B, 7, generator=torch.Generator().manual_seed(4)).to(dev()) if cond else None
+  args = dict(sample=w, deterministic=False)
+  if cond:
+    args['condition'] = c
+  naive = model.generate(40, use_queues=False, **args)
+  L = _lib.lib()
+  for knob in (0, 2, 1):
+    try:
+      L.wn_debug_set(34, knob)
+      queued = model.generate(40, use_queues=True, **args)
+    finally:
+      L.wn_debug_set(34, 0)
+    assert torch.equal(naive, queued), (knob, (naive - queued).abs().max())
+
+
 def test_plan_caches_survive_shape_changes():
   """One model object through training and generation at changing batch sizes / lengths: the plan's
   cached device tables (weight-gradient jobs, generation block table) are keyed by shape."""
