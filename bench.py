@@ -451,7 +451,7 @@ def main():
         'final_loss': logs['loss'],
         'roofline': {'bound': 'hbm',
                      'kernel': 'residual-block stack forward: 30 x wn_layer_fwd_f16_kernel + the folded contraction over all '
-                               "blocks' gated activations (wn_gemm_rows16_kernel<4>: skip sum and, in training passes, the head's "
+                               "blocks' gated activations (wn_gemm_planes16s_kernel: skip sum and, in training passes, the head's "
                                'first conv in one product), SURVEY.md 8(d)',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
