@@ -255,6 +255,12 @@ MODEL_CASES = {
                          dilation_bound=9, final_layers_channels=[9], activation='relu', bits=5),
     'cat_lpb3': dict(blocks=3, layers_per_block=3, channels=32, skip_channels=32, dilation_bound=8,
                      final_layers_channels=[32], activation='tanh', bits=6),
+    # deeper stacks on the split-precision training path (deep16): 64 channels (unpadded images, INNER<2> weight gradients)
+    # and kernel size 3 (inner gradients' max-abs slots feeding the generic job table)
+    'cat_lpb2_r64': dict(blocks=3, layers_per_block=2, channels=64, skip_channels=64, dilation_bound=8,
+                         final_layers_channels=[64], activation='leaky_relu', bits=8),
+    'cat_lpb2_k3_r32': dict(blocks=3, layers_per_block=2, kernel_size=3, channels=32, skip_channels=32, dilation_bound=9,
+                            final_layers_channels=[32], activation='relu', bits=6),
     'cat_k3': dict(blocks=4, kernel_size=3, channels=32, skip_channels=32, dilation_bound=9,
                    final_layers_channels=[], bits=6),
     'cat_noskip_nores': dict(blocks=3, channels=32, skip_channels=32, dilation_bound=4, use_skip=False,
