@@ -1,6 +1,6 @@
-// Rows contraction over a PLANAR operand with 128 output columns, streamed weights, second form (gfx950):
-//   Y[t][n] = act( b[n] + sum_p sum_k Z_p[t][k] * W[p * PK + k][n] ),   n < 128, p < NP planes of PK channels each.
-// Its user is the folded skip contraction of a training pass: the skip sum over all blocks' gated activations
+// Rows contraction over a PLANAR operand with 128 or 256 output columns, streamed weights, second form (gfx950):
+//   Y[t][n] = act( b[n] + sum_p sum_k Z_p[t][k] * W[p * PK + k][n] ),   n < N, p < NP planes of PK channels each.
+// Users: the head's 1x1 convs with 128 / 256 outputs (one plane; src/model.py:105-119) and the folded skip contraction: the skip sum over all blocks' gated activations
 // (src/layers.py:216-217, src/model.py:235-236) folded with the head's first conv (src/model.py:105-111): K = N_blocks * D.
 //
 // Same arithmetic as wn_gemm_rows16_kernel<4, PLAIN> on the same fp16 hi|lo image -- accumulators from zero, k ascending,
@@ -21,15 +21,15 @@ using namespace wn_stream;
 
 namespace {
 
-template <int RT>
+template <int RT, int JT_>
 struct GS {
-  static constexpr int JT = 4;                         // column tiles (128 outputs)
+  static constexpr int JT = JT_;                       // column tiles: 4 (128 outputs, two row tiles per wave) or 8 (256, one)
   static constexpr int CHUNK = JT * 2048, NBUF = 3;    // one k-step of weights
   static constexpr int XB = 3, XBUF = RT * 2048;       // a wave's activations of one k-step
   static constexpr int WAVES = 4, THREADS = 256;
   static constexpr int PITCH = 36, STAGE = 32 * PITCH * 4;
   static constexpr int REGION = XB * XBUF;             // per wave: activation ring, reused as the output stage
-  static constexpr int LDS = NBUF * CHUNK + WAVES * REGION + 128 * 4;    // + bias table
+  static constexpr int LDS = NBUF * CHUNK + WAVES * REGION + 32 * JT * 4;    // + bias table
   static constexpr int PT = CHUNK / 16 / THREADS;      // weight requests per thread and k-step (2)
   static constexpr int PX = 2 * RT;                    // activation requests per lane and k-step
   static_assert(STAGE <= REGION, "the output stage lives in the activation ring");
@@ -38,9 +38,9 @@ struct GS {
 }  // namespace
 
 // ACT >= 0: the activation fixed at compile time (linear / relu / leaky relu: straight-line epilogue); -1: a.act at run time
-template <int RT, int ACT>
+template <int RT, int JT_, int ACT>
 __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesArgs a) {
-  using C = GS<RT>;
+  using C = GS<RT, JT_>;
   constexpr int JT = C::JT, PT = C::PT, PX = C::PX, PITCH = C::PITCH;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
   const int tid = threadIdx.x;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
   float* stage = reinterpret_cast<float*>(xbuf);
   const unsigned smem_addr = lds_addr_of(smem), xbuf_addr = lds_addr_of(xbuf);
   float* sbias = reinterpret_cast<float*>(smem + C::NBUF * C::CHUNK + C::WAVES * C::REGION);
-  if (tid < 128) sbias[tid] = a.bias ? a.bias[tid] : 0.f;
+  if (tid < 32 * JT) sbias[tid] = a.bias ? a.bias[tid] : 0.f;
   const bool has_bias = a.bias != nullptr;
   __syncthreads();
 
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
 }
 
 int wn_gemm_planes16s_supported(int N, int plane_k, int nplanes, int ld, int ldy) {
-  return N == 128 && plane_k >= 16 && plane_k % 16 == 0 && nplanes * (plane_k / 16) >= 3 && ld % 4 == 0 && ld >= plane_k && ldy % 4 == 0 &&
-         ldy >= 128;
+  return (N == 128 || N == 256) && plane_k >= 16 && plane_k % 16 == 0 && nplanes * (plane_k / 16) >= 3 && ld % 4 == 0 && ld >= plane_k && ldy % 4 == 0 &&
+         ldy >= N;
 }
 
 int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
@@ -212,17 +212,24 @@ int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
   }
   if ((int64_t)a.B * a.T * a.ld * 4 >= (int64_t)1 << 32) { wn_set_error("gemm_planes16s: plane beyond 4 GiB"); return WN_E_UNSUPPORTED; }
   if ((int64_t)a.B * a.T <= 0) return WN_OK;
-  const int rt = wn_debug_get(30) == 1 ? 1 : 2;          // knob 30 = 1: one row tile per wave (A/B)
+  // 128 columns: two row tiles per wave (knob 30 = 1: one, A/B); 256 columns: one (128 accumulator registers either way)
+  const int rt = (a.N == 256 || wn_debug_get(30) == 1) ? 1 : 2;
   const int64_t tiles = (int64_t)a.B * ((a.T + 32 * rt - 1) / (32 * rt));
   int64_t gx = (tiles + 3) / 4;
   if (gx > 512) gx = 512;                                // two persistent workgroups of four waves per CU
-#define WN_GS_LAUNCH(RT_, ACT_) hipLaunchKernelGGL((wn_gemm_planes16s_kernel<RT_, ACT_>), dim3((unsigned)gx), dim3(256), 0, s, a)
-  if (rt == 1) WN_GS_LAUNCH(1, -1);
+#define WN_GS_LAUNCH(RT_, JT_, ACT_) hipLaunchKernelGGL((wn_gemm_planes16s_kernel<RT_, JT_, ACT_>), dim3((unsigned)gx), dim3(256), 0, s, a)
+  if (a.N == 256) switch (a.act) {
+    case WN_ACT_LINEAR: WN_GS_LAUNCH(1, 8, WN_ACT_LINEAR); break;
+    case WN_ACT_RELU: WN_GS_LAUNCH(1, 8, WN_ACT_RELU); break;
+    case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH(1, 8, WN_ACT_LEAKY_RELU); break;
+    default: WN_GS_LAUNCH(1, 8, -1); break;
+  }
+  else if (rt == 1) WN_GS_LAUNCH(1, 4, -1);
   else switch (a.act) {
-    case WN_ACT_LINEAR: WN_GS_LAUNCH(2, WN_ACT_LINEAR); break;
-    case WN_ACT_RELU: WN_GS_LAUNCH(2, WN_ACT_RELU); break;
-    case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH(2, WN_ACT_LEAKY_RELU); break;
-    default: WN_GS_LAUNCH(2, -1); break;
+    case WN_ACT_LINEAR: WN_GS_LAUNCH(2, 4, WN_ACT_LINEAR); break;
+    case WN_ACT_RELU: WN_GS_LAUNCH(2, 4, WN_ACT_RELU); break;
+    case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH(2, 4, WN_ACT_LEAKY_RELU); break;
+    default: WN_GS_LAUNCH(2, 4, -1); break;
   }
 #undef WN_GS_LAUNCH
   WN_HIP_CHECK(hipGetLastError());

@@ -1699,6 +1699,20 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     const ConvInfo& c = p->finals[i];
     const bool last = (i + 1 == p->finals.size());
     float* dst = last ? ws + L.logits : ws + L.HA[i];
+    // 128 / 256 output columns: the streamed kernel's second form (wn_gemm16s.hip; the operand is one "plane"); same
+    // products in the same order as the rows GEMM below (knob 31 = 1)
+    if (c.frag16 >= 0 && wn_debug_get(1) != 1 && wn_debug_get(31) != 1 && wn_gemm_planes16s_supported(c.cout, hc, 1, hc, c.cout) &&
+        (int64_t)rows * hc * 4 < ((int64_t)1 << 32)) {
+      WnGemmPlanesArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.z = hin; ga.plane_stride = 0; ga.ld = hc; ga.plane_k = hc; ga.nplanes = 1;
+      ga.w16 = fragbase + c.frag16; ga.bias = params + p->tensors[c.bias_t].off; ga.act = last ? WN_ACT_LINEAR : p->c.activation;
+      ga.y = dst; ga.ldy = c.cout; ga.N = c.cout; ga.B = B; ga.T = T; ga.absmax_out = last ? nullptr : fam;
+      rc = wn_launch_gemm_planes16s(ga, s);
+      if (rc) return rc;
+      hin = dst; hc = c.cout;
+      continue;
+    }
     rc = Gemm(B, T, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
              .w16(c.frag16 >= 0 ? fragbase + c.frag16 : nullptr)
              .bias(params + p->tensors[c.bias_t].off).act(last ? WN_ACT_LINEAR : p->c.activation)
