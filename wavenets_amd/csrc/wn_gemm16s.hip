@@ -37,7 +37,10 @@ struct GS {
 
 }  // namespace
 
-// ACT >= 0: the activation fixed at compile time (linear / relu / leaky relu: straight-line epilogue); -1: a.act at run time
+// ACT >= 0: the activation fixed at compile time (linear / relu / leaky relu: straight-line epilogue); -1: a.act at run time;
+// -2: the backward-data form -- the operand is a gradient, scaled by an exact power of two from its running max-abs
+// (a.absmax_in) like wn_gemm_rows16_kernel does, the epilogue multiplies by act'(saved output) (a.aux) instead of applying
+// act, the result's max-abs goes to a gradient slot
 template <int RT, int JT_, int ACT>
 __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesArgs a) {
   using C = GS<RT, JT_>;
@@ -53,6 +56,17 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
   if (tid < 32 * JT) sbias[tid] = a.bias ? a.bias[tid] : 0.f;
   const bool has_bias = a.bias != nullptr;
   __syncthreads();
+  float sc = 1.0f, inv_sc = 1.0f;
+  if (ACT == -2 && a.absmax_in) {
+    const float m = *a.absmax_in;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);               // m = f * 2^e, f in [0.5, 1)
+      e = max(-100, min(100, e));
+      sc = ldexpf(1.0f, -e);             // scaled values lie in [-1, 1)
+      inv_sc = ldexpf(1.0f, e);
+    }
+  }
 
   const int kpp = a.plane_k >> 4;                      // k-steps per plane
   const int nsteps = a.nplanes * kpp;                  // >= 3 (launcher)
@@ -136,7 +150,8 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
       for (int rt = 0; rt < RT; ++rt) {
         f32x4 q0 = xl[rt * 128], q1 = xl[rt * 128 + 64];
         if (!xok[rt]) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
-        split8(q0, q1, bh[rt], bl[rt]);
+        if constexpr (ACT == -2) split8s(q0, q1, sc, bh[rt], bl[rt]);
+        else split8(q0, q1, bh[rt], bl[rt]);
       }
       h8 fr[2][2];
       fr[0][0] = wl[0];
@@ -178,12 +193,24 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
         for (int rq = 0; rq < 4; ++rq) {
           const int n0 = 32 * j + 8 * rq + 4 * h;
           float v[4] = {acc[rt][j][4 * rq + 0], acc[rt][j][4 * rq + 1], acc[rt][j][4 * rq + 2], acc[rt][j][4 * rq + 3]};
+          if constexpr (ACT == -2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= inv_sc;
+          }
           if (has_bias) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + n0);
             v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
           }
+          if constexpr (ACT == -2) {
+            if (a.aux && xok[rt]) {
+              const f32x4 yv = *(const __attribute__((address_space(1))) f32x4*)(a.aux + (row0 + 32 * rt + tl) * a.ld_aux + n0);
+              v[0] *= wn_dact_from_y(yv.x, a.act); v[1] *= wn_dact_from_y(yv.y, a.act);
+              v[2] *= wn_dact_from_y(yv.z, a.act); v[3] *= wn_dact_from_y(yv.w, a.act);
+            }
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], ACT >= 0 ? ACT : a.act);
+            for (int e = 0; e < 4; ++e) v[e] = wn_act(v[e], ACT >= 0 ? ACT : a.act);
+          }
           if (xok[rt]) wmax = wn_absmax_acc(wmax, v[0], v[1], v[2], v[3]);
           acc[rt][j][4 * rq + 0] = v[0]; acc[rt][j][4 * rq + 1] = v[1]; acc[rt][j][4 * rq + 2] = v[2]; acc[rt][j][4 * rq + 3] = v[3];
         }
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead k-steps land before the LDS is given back
   if (a.absmax_out) {
     wmax = wn_wave_absmax_bits(wmax);
-    if (lane == 0) wn_absmax_publish_any(a.absmax_out, wmax);
+    if (lane == 0) { if (ACT == -2) wn_absmax_publish(a.absmax_out, wmax); else wn_absmax_publish_any(a.absmax_out, wmax); }
   }
 }
 
@@ -218,7 +245,10 @@ int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
   int64_t gx = (tiles + 3) / 4;
   if (gx > 512) gx = 512;                                // two persistent workgroups of four waves per CU
 #define WN_GS_LAUNCH(RT_, JT_, ACT_) hipLaunchKernelGGL((wn_gemm_planes16s_kernel<RT_, JT_, ACT_>), dim3((unsigned)gx), dim3(256), 0, s, a)
-  if (a.N == 256) switch (a.act) {
+  if (a.bwd) {
+    if (a.N == 256) WN_GS_LAUNCH(1, 8, -2);
+    else WN_GS_LAUNCH(2, 4, -2);
+  } else if (a.N == 256) switch (a.act) {
     case WN_ACT_LINEAR: WN_GS_LAUNCH(1, 8, WN_ACT_LINEAR); break;
     case WN_ACT_RELU: WN_GS_LAUNCH(1, 8, WN_ACT_RELU); break;
     case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH(1, 8, WN_ACT_LEAKY_RELU); break;

@@ -83,7 +83,12 @@ struct WnGemmPlanesArgs {
   float* y; int32_t ldy;
   int32_t N;               // 128
   int32_t B, T;
-  float* absmax_out;       // forward range-guard slot or null
+  float* absmax_out;       // forward range-guard slot (bwd: the result's gradient max-abs slot) or null
+  // bwd = 1: backward-data form: operand scaled by the power of two of *absmax_in, epilogue * act'(aux[row][n]) when aux
+  // is given (act = the forward activation), no bias
+  int32_t bwd;
+  const float* absmax_in;
+  const float* aux; int32_t ld_aux;
 };
 int wn_gemm_planes16s_supported(int N, int plane_k, int nplanes, int ld, int ldy);
 int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s);

@@ -2187,9 +2187,24 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     float* head_out = p->c.use_skip ? ws + L.g_skipsum : ws + L.GH[p->N];
     for (int i = (int)p->finals.size() - 1; i >= (fold ? 1 : 0); --i) {
       const ConvInfo& c = p->finals[i];
+      float* dst = (i == 0) ? head_out : ws + L.GF[i - 1];
+      // 128 / 256 input channels: the streamed kernel's second form in its backward-data instantiation (knob 31 = 1: rows GEMM)
+      if (c.frag16B >= 0 && wn_debug_get(1) != 1 && wn_debug_get(31) != 1 && wn_gemm_planes16s_supported(c.cin, c.cout, 1, c.cout, c.cin) &&
+          (int64_t)rows * c.cout * 4 < ((int64_t)1 << 32)) {
+        WnGemmPlanesArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.z = ws + L.GF[i]; ga.ld = c.cout; ga.plane_k = c.cout; ga.nplanes = 1;
+        ga.w16 = fragbase + c.frag16B; ga.act = p->c.activation;
+        ga.y = dst; ga.ldy = c.cin; ga.N = c.cin; ga.B = B; ga.T = T;
+        ga.bwd = 1; ga.absmax_in = am_GF(i);
+        ga.absmax_out = i > 0 ? am_GF(i - 1) : (p->c.use_skip ? am_gskip : am_GH(p->N));
+        if (i > 0) { ga.aux = ws + L.HA[i - 1]; ga.ld_aux = c.cin; }
+        rc = wn_launch_gemm_planes16s(ga, s);
+        if (rc) return rc;
+        continue;
+      }
       Gemm gm(B, T, c.cin, ceil32(c.cin));
       gm.seg(ws + L.GF[i], c.cout, c.cout, 0, fragbase + c.fragB);
-      float* dst = (i == 0) ? head_out : ws + L.GF[i - 1];
       if (i > 0) gm.dact(ws + L.HA[i - 1], c.cin, p->c.activation);
       if (c.frag16B >= 0)
         gm.w16(fragbase + c.frag16B).absmax(am_GF(i), nullptr, i > 0 ? am_GF(i - 1) : (p->c.use_skip ? am_gskip : am_GH(p->N)));

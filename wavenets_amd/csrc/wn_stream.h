@@ -25,6 +25,18 @@ __device__ __forceinline__ void split8(const f32x4& q0, const f32x4& q1, h8& hi,
   }
 }
 
+// the same with the operand scaled by s (an exact power of two): hi = fp16(q s), lo = fp16(q s - hi) with the product
+// unrounded -- wn_split8g of wn_gemm16.hip
+__device__ __forceinline__ void split8s(const f32x4& q0, const f32x4& q1, float s, h8& hi, h8& lo) {
+  const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)(v[e] * s);
+    hi[e] = h;
+    lo[e] = (_Float16)__builtin_fmaf(v[e], s, -(float)h);
+  }
+}
+
 // LDS-DMA of 16 bytes per lane: global address = scalar base + 32-bit lane offset, LDS address = M0 + lane * 16.
 // Inline assembly on purpose: through the builtin hipcc forms every address as a 64-bit VGPR pair, hoists the pairs out of
 // the loop, spills them and reloads each with s_waitcnt vmcnt(0) in front of its request.  The
