@@ -41,7 +41,10 @@ struct GS {
 // -2: the backward-data form -- the operand is a gradient, scaled by an exact power of two from its running max-abs
 // (a.absmax_in) like wn_gemm_rows16_kernel does, the epilogue multiplies by act'(saved output) (a.aux) instead of applying
 // act, the result's max-abs goes to a gradient slot
-template <int RT, int JT_, int ACT>
+// SHIFT: the planes are the taps of a dilated conv over ONE tensor (plane_stride 0): plane p reads row t - a.shift[p] of the
+// same utterance, rows outside [0, T) contribute zero (src/layers.py:66-88 causal padding; negative shifts: its backward).
+// JT = 2 serves 32 and 64 output channels (a.N; a 32-channel image is padded to two row tiles, see wn_gemm_rows16_ok).
+template <int RT, int JT_, int ACT, bool SHIFT = false>
 __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesArgs a) {
   using C = GS<RT, JT_>;
   constexpr int JT = C::JT, PT = C::PT, PX = C::PX, PITCH = C::PITCH;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
   float* stage = reinterpret_cast<float*>(xbuf);
   const unsigned smem_addr = lds_addr_of(smem), xbuf_addr = lds_addr_of(xbuf);
   float* sbias = reinterpret_cast<float*>(smem + C::NBUF * C::CHUNK + C::WAVES * C::REGION);
-  if (tid < 32 * JT) sbias[tid] = a.bias ? a.bias[tid] : 0.f;
+  if (tid < 32 * JT) sbias[tid] = (a.bias && tid < a.N) ? a.bias[tid] : 0.f;
   const bool has_bias = a.bias != nullptr;
   __syncthreads();
   float sc = 1.0f, inv_sc = 1.0f;
@@ -111,16 +114,26 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
     }
     // the activation stream of this tile: k-step xs_k of plane base xs_base goes to activation buffer xs_buf
     const char* xs_base = reinterpret_cast<const char*>(a.z);
-    int xs_k = 0, xs_buf = 0;                          // scalar
+    int xs_k = 0, xs_buf = 0, xs_p = 0;                // scalar
+    // SHIFT: this lane's row of plane p (clamped; rows outside the utterance are zeroed at use)
+    auto shifted = [&](int rt, int pl, bool& ok) -> unsigned {
+      // (selects, not an indexed read: a runtime index would move the argument array to scratch)
+      const int sh = pl == 0 ? a.shift[0] : (pl == 1 ? a.shift[1] : (pl == 2 ? a.shift[2] : a.shift[3]));
+      const int t = t0 + 32 * rt + tl, ts = t - sh;
+      ok = live && t < a.T && ts >= 0 && ts < a.T;
+      return (unsigned)(((int64_t)b * a.T + (ok ? ts : 0)) * a.ld + 4 * h) * 4u;
+    };
     auto xdma = [&]() {
       const char* base = xs_base + 64 * xs_k;
       const unsigned dst = xbuf_addr + xs_buf * C::XBUF;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        dma16(base, xoff[rt], dst + rt * 2048);
-        dma16(base + 32, xoff[rt], dst + rt * 2048 + 1024);
+        bool okd;
+        const unsigned off = SHIFT ? shifted(rt, xs_p, okd) : xoff[rt];
+        dma16(base, off, dst + rt * 2048);
+        dma16(base + 32, off, dst + rt * 2048 + 1024);
       }
-      if (++xs_k == kpp) { xs_k = 0; xs_base += a.plane_stride * 4; }
+      if (++xs_k == kpp) { xs_k = 0; xs_base += a.plane_stride * 4; ++xs_p; }
       xs_buf = xs_buf + 1 == C::XB ? 0 : xs_buf + 1;
     };
 
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
     xdma();
     xdma();
     int xcur = 0;                                      // activation buffer of the current step (scalar)
+    int cs_k = 0, cs_p = 0;                            // k-step inside the plane and plane of the current step (SHIFT)
     // WAIT = loads younger than x(c); XNEXT: x(c + 2) exists
     auto step = [&](auto wait_, bool xnext) {
       constexpr int WAIT = decltype(wait_)::value;
@@ -149,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         f32x4 q0 = xl[rt * 128], q1 = xl[rt * 128 + 64];
-        if (!xok[rt]) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+        bool okc = xok[rt];
+        if constexpr (SHIFT) (void)shifted(rt, cs_p, okc);
+        if (!okc) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
         if constexpr (ACT == -2) split8s(q0, q1, sc, bh[rt], bl[rt]);
         else split8(q0, q1, bh[rt], bl[rt]);
       }
@@ -176,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
       wadvance();
       slot = slot + 1 == C::NBUF ? 0 : slot + 1;
       xcur = xcur + 1 == C::XB ? 0 : xcur + 1;
+      if (++cs_k == kpp) { cs_k = 0; ++cs_p; }
     };
     step(std::integral_constant<int, PX>{}, true);                                   // c = 0: younger = x(1)
     for (int c = 1; c + 1 < nsteps; ++c) step(std::integral_constant<int, PT + PX>{}, c + 2 < nsteps);
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
       if (rows_valid <= 0) continue;
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
+        if (32 * j >= a.N) continue;                     // (padded image: the second row tile of a 32-channel output)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const int n0 = 32 * j + 8 * rq + 4 * h;
@@ -227,25 +245,43 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
   }
 }
 
+// the shifted-plane form: 32 / 64 output channels, the planes are <= 4 taps of one tensor
+int wn_gemm_taps16s_supported(int N, int plane_k, int ntaps, int ld, int ldy) {
+  return (N == 32 || N == 64) && ntaps >= 1 && ntaps <= 4 && plane_k >= 16 && plane_k % 16 == 0 && ntaps * (plane_k / 16) >= 3 &&
+         ld % 4 == 0 && ld >= plane_k && ldy % 4 == 0 && ldy >= N;
+}
+
 int wn_gemm_planes16s_supported(int N, int plane_k, int nplanes, int ld, int ldy) {
   return (N == 128 || N == 256) && plane_k >= 16 && plane_k % 16 == 0 && nplanes * (plane_k / 16) >= 3 && ld % 4 == 0 && ld >= plane_k && ldy % 4 == 0 &&
          ldy >= N;
 }
 
 int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
-  if (!wn_gemm_planes16s_supported(a.N, a.plane_k, a.nplanes, a.ld, a.ldy)) {
+  if (!(a.nshift > 0 ? wn_gemm_taps16s_supported(a.N, a.plane_k, a.nplanes, a.ld, a.ldy)
+                     : wn_gemm_planes16s_supported(a.N, a.plane_k, a.nplanes, a.ld, a.ldy))) {
     wn_set_error("gemm_planes16s: unsupported shape N=%d plane_k=%d planes=%d", a.N, a.plane_k, a.nplanes);
     return WN_E_UNSUPPORTED;
   }
   if ((int64_t)a.B * a.T * a.ld * 4 >= (int64_t)1 << 32) { wn_set_error("gemm_planes16s: plane beyond 4 GiB"); return WN_E_UNSUPPORTED; }
   if ((int64_t)a.B * a.T <= 0) return WN_OK;
   // 128 columns: two row tiles per wave (knob 30 = 1: one, A/B); 256 columns: one (128 accumulator registers either way)
-  const int rt = (a.N == 256 || wn_debug_get(30) == 1) ? 1 : 2;
+  const int rt = a.N <= 64 ? 2 : ((a.N == 256 || wn_debug_get(30) == 1) ? 1 : 2);
   const int64_t tiles = (int64_t)a.B * ((a.T + 32 * rt - 1) / (32 * rt));
   int64_t gx = (tiles + 3) / 4;
   if (gx > 512) gx = 512;                                // two persistent workgroups of four waves per CU
 #define WN_GS_LAUNCH(RT_, JT_, ACT_) hipLaunchKernelGGL((wn_gemm_planes16s_kernel<RT_, JT_, ACT_>), dim3((unsigned)gx), dim3(256), 0, s, a)
-  if (a.bwd) {
+#define WN_GS_LAUNCH_S(ACT_) hipLaunchKernelGGL((wn_gemm_planes16s_kernel<2, 2, ACT_, true>), dim3((unsigned)gx), dim3(256), 0, s, a)
+  if (a.N <= 64) {
+    // the convs of a stack deeper than 1 (32 / 64 output channels, taps as shifted planes of one tensor)
+    if (a.nshift != a.nplanes || a.plane_stride != 0 || a.nplanes > 4) { wn_set_error("gemm_planes16s: narrow outputs are the shifted form"); return WN_E_UNSUPPORTED; }
+    if (a.bwd) WN_GS_LAUNCH_S(-2);
+    else switch (a.act) {
+      case WN_ACT_LINEAR: WN_GS_LAUNCH_S(WN_ACT_LINEAR); break;
+      case WN_ACT_RELU: WN_GS_LAUNCH_S(WN_ACT_RELU); break;
+      case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH_S(WN_ACT_LEAKY_RELU); break;
+      default: WN_GS_LAUNCH_S(-1); break;
+    }
+  } else if (a.bwd) {
     if (a.N == 256) WN_GS_LAUNCH(1, 8, -2);
     else WN_GS_LAUNCH(2, 4, -2);
   } else if (a.N == 256) switch (a.act) {
@@ -262,6 +298,7 @@ int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
     default: WN_GS_LAUNCH(2, 4, -1); break;
   }
 #undef WN_GS_LAUNCH
+#undef WN_GS_LAUNCH_S
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

@@ -89,8 +89,12 @@ struct WnGemmPlanesArgs {
   int32_t bwd;
   const float* absmax_in;
   const float* aux; int32_t ld_aux;
+  // nshift == nplanes (<= 4) with plane_stride 0: plane p reads row t - shift[p] of its utterance (the taps of a dilated
+  // conv, or of its backward with negative shifts); rows outside [0, T) contribute zero.  Outputs of 32 / 64 channels only.
+  int32_t nshift; int32_t shift[4];
 };
 int wn_gemm_planes16s_supported(int N, int plane_k, int nplanes, int ld, int ldy);
+int wn_gemm_taps16s_supported(int N, int plane_k, int ntaps, int ld, int ldy);
 int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- weight-gradient GEMM

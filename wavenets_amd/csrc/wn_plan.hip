@@ -676,6 +676,21 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
   if (f.pre_done && k.depth > 1) { h = nullptr; hc = k.D; }
   for (int i = 0; i + 1 < k.depth && !f.pre_done; ++i) {
     const bool i16 = k.F16i[i] != nullptr;            // (training passes of deep stacks: split-precision, see deep16_ptrs)
+    // 32 / 64 channels: the streamed kernel's second form with the taps as shifted planes (knob 36 = 1: the rows GEMM)
+    if (i16 && k.JTi[i] == 2 && k.KS <= 4 && wn_debug_get(36) != 1 && wn_gemm_taps16s_supported(k.D, hc, k.KS, hc, k.D) &&
+        (int64_t)rows * hc * 4 < ((int64_t)1 << 32)) {
+      WnGemmPlanesArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.z = h; ga.plane_stride = 0; ga.ld = hc; ga.plane_k = hc; ga.nplanes = k.KS;
+      ga.nshift = k.KS;
+      for (int t = 0; t < k.KS; ++t) ga.shift[t] = (k.KS - 1 - t) * k.dil[i];
+      ga.w16 = k.F16i[i]; ga.bias = k.bd[i]; ga.act = k.act;
+      ga.y = f.P[i]; ga.ldy = k.D; ga.N = k.D; ga.B = k.B; ga.T = k.T;
+      rc = wn_launch_gemm_planes16s(ga, s);
+      if (rc) return rc;
+      h = f.P[i]; hc = k.D;
+      continue;
+    }
     Gemm g(k.B, k.T, k.D, i16 ? k.JTi[i] : ceil32(k.D));
     for (int t = 0; t < k.KS; ++t) g.seg(h, hc, hc, (k.KS - 1 - t) * k.dil[i], i16 ? nullptr : k.Fd[i] + t * k.Fd_stride[i]);
     if (i16) g.w16(k.F16i[i]);
@@ -883,6 +898,24 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     const float* am_cur = (i == li) ? g.am_gu : g.am_gp[i];
     float* am_dst = (i > 0) ? g.am_gp[i - 1] : g.am_gx;
     const bool b16 = k.depth > 1 && k.G16i[i] && am_cur && am_dst;
+    // inner convs (their output gradient gets act' folded in): the streamed kernel's second form, backward-data
+    // instantiation with the taps as negatively shifted planes (knob 36 = 1: the rows GEMM)
+    if (b16 && i > 0 && k.JTb[i] == 2 && k.KS <= 4 && wn_debug_get(36) != 1 && wn_gemm_taps16s_supported(hc, gc, k.KS, gc, hc) &&
+        (int64_t)rows * gc * 4 < ((int64_t)1 << 32)) {
+      float* dst = g.g_pi[i - 1] ? g.g_pi[i - 1] : g.g_p + (int64_t)((i & 1) ? 0 : rows * k.D);
+      WnGemmPlanesArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.z = gcur; ga.plane_stride = 0; ga.ld = gc; ga.plane_k = gc; ga.nplanes = k.KS;
+      ga.nshift = k.KS;
+      for (int t = 0; t < k.KS; ++t) ga.shift[t] = -(k.KS - 1 - t) * k.dil[i];
+      ga.w16 = k.G16i[i]; ga.act = k.act;
+      ga.y = dst; ga.ldy = hc; ga.N = hc; ga.B = k.B; ga.T = k.T;
+      ga.bwd = 1; ga.absmax_in = am_cur; ga.absmax_out = am_dst; ga.aux = f.P[i - 1]; ga.ld_aux = k.D;
+      rc = wn_launch_gemm_planes16s(ga, s);
+      if (rc) return rc;
+      gcur = dst; gc = k.D;
+      continue;
+    }
     Gemm gm(k.B, k.T, hc, b16 ? k.JTb[i] : ceil32(hc));
     for (int t = 0; t < k.KS; ++t)
       gm.seg(gcur, gc, gc, -(k.KS - 1 - t) * k.dil[i], b16 ? nullptr : k.Bd[i] + t * k.Bd_stride[i]);
