@@ -6,14 +6,41 @@
 
 // ------------------------------------------------------------------------------------------
 // wave-per-row helpers
+// Reductions over the 64 lanes on the DPP cross-lane operands of the VALU (no LDS round trips: __shfl_xor is a ds_bpermute
+// with its own address and wait, six in a row per reduction): quad butterflies, then the two mirror permutations leave
+// every lane with the sum / max of its row of 16; the four row results are read as scalars.  Every lane returns the result.
+// (All 64 lanes must be active, as with the shuffles.)
+#define WN_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
 __device__ __forceinline__ float wn_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, WN_DPP_F(v, 0xB1));                  // quad_perm [1, 0, 3, 2]
+  v = fmaxf(v, WN_DPP_F(v, 0x4E));                  // quad_perm [2, 3, 0, 1]
+  v = fmaxf(v, WN_DPP_F(v, 0x141));                 // row_half_mirror
+  v = fmaxf(v, WN_DPP_F(v, 0x140));                 // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 __device__ __forceinline__ float wn_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += WN_DPP_F(v, 0xB1);
+  v += WN_DPP_F(v, 0x4E);
+  v += WN_DPP_F(v, 0x141);
+  v += WN_DPP_F(v, 0x140);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+// inclusive prefix sum over the lanes: shifts by 1, 2, 4, 8 inside the rows of 16 (lanes without a source add zero), then
+// the last lane of rows 0 / 2 into rows 1 / 3 and lane 31 into the upper half
+#define WN_DPP_Z(v, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float wn_wave_scan_incl(float v) {
+  v += WN_DPP_Z(v, 0x111, 0xf);                     // row_shr:1
+  v += WN_DPP_Z(v, 0x112, 0xf);                     // row_shr:2
+  v += WN_DPP_Z(v, 0x114, 0xf);                     // row_shr:4
+  v += WN_DPP_Z(v, 0x118, 0xf);                     // row_shr:8
+  v += WN_DPP_Z(v, 0x142, 0xa);                     // row_bcast:15 into rows 1, 3
+  v += WN_DPP_Z(v, 0x143, 0xc);                     // row_bcast:31 into rows 2, 3
   return v;
 }
 
@@ -42,13 +69,8 @@ __device__ __forceinline__ int wn_draw_cat_row(P p, int C, int lane, int64_t row
   const int j0 = lane * per;
   float loc = 0.f;
   for (int j = j0; j < min(C, j0 + per); ++j) loc += fmaxf(p[j], 0.f);
-  float incl = loc;                            // inclusive scan over lanes
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float v = __shfl_up(incl, o);
-    if (lane >= o) incl += v;
-  }
-  const float total = __shfl(incl, 63);
+  const float incl = wn_wave_scan_incl(loc);   // inclusive scan over lanes
+  const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
   uint32_t r[4];
   wn_philox((uint64_t)row, offset, seed, r);
   const float target = wn_u01(r[0]) * total;
