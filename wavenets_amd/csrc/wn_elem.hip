@@ -1069,10 +1069,14 @@ __global__ __launch_bounds__(256) void wn_sgemm_small_kernel(const float* A, int
 // one launch); bias (+ activation) = the Dense epilogue of the conditioning's mapping stack (src/model.py:121-135).
 __global__ __launch_bounds__(256) void wn_sgemm_small32_kernel(const float* A, int64_t sai, int64_t sak, const float* B, int64_t sbk,
                                                                int64_t sbj, float* C, int ldc, int M, int N, int K,
-                                                               int64_t za, int64_t zb, int64_t zc, const float* bias, int act) {
+                                                               int64_t za, int64_t zb, int64_t zc, const float* bias, int act,
+                                                               int zk) {
   constexpr int KC = 128;
   __shared__ float As[KC][32 + 1], Bs[KC][32 + 1];
   A += (int64_t)blockIdx.z * za; B += (int64_t)blockIdx.z * zb; C += (int64_t)blockIdx.z * zc;
+  // zk > 0: split K -- product z covers k in [z zk, min(K, (z + 1) zk)) of ONE long contraction (za / zb advance the
+  // operands by zk rows of k); the partial results are summed by the caller
+  if (zk > 0) K = max(0, min(K - (int)blockIdx.z * zk, zk));
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // outputs (ty + 8 a, tx), a < 4
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1121,7 +1125,7 @@ int wn_launch_sgemm_small(const float* A, int64_t sai, int64_t sak, const float*
   if (M <= 0 || N <= 0) return WN_OK;
   if (wn_debug_get(32) != 1) {                             // knob 32 = 1: the 64 x 64 form (A/B, bit-identity test)
     hipLaunchKernelGGL(wn_sgemm_small32_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, sai, sak, B, sbk, sbj, C,
-                       ldc, M, N, K, (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr, 0);
+                       ldc, M, N, K, (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr, 0, 0);
     WN_HIP_CHECK(hipGetLastError());
     return WN_OK;
   }
@@ -1134,11 +1138,11 @@ int wn_launch_sgemm_small(const float* A, int64_t sai, int64_t sak, const float*
 // nz products in one launch (bases za / zb / zc floats apart), optional Dense epilogue C = act(A B + bias)
 int wn_launch_sgemm_small_batched(const float* A, int64_t sai, int64_t sak, int64_t za, const float* B, int64_t sbk, int64_t sbj,
                                   int64_t zb, float* C, int ldc, int64_t zc, int M, int N, int K, int nz, const float* bias,
-                                  int act, hipStream_t s) {
+                                  int act, hipStream_t s, int zk) {
   if (M <= 0 || N <= 0 || nz <= 0) return WN_OK;
   if (nz > 65535) { wn_set_error("sgemm_small_batched: too many products"); return WN_E_UNSUPPORTED; }
   hipLaunchKernelGGL(wn_sgemm_small32_kernel, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(256), 0, s, A, sai, sak, B, sbk, sbj, C,
-                     ldc, M, N, K, za, zb, zc, bias, act);
+                     ldc, M, N, K, za, zb, zc, bias, act, zk);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;
 }

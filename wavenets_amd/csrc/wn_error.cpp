@@ -54,6 +54,7 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //   34  = 1: queued generation of 128-channel blocks on the streamed forward kernel, one launch per block;
 //       = 2: on wn_gen_block128_kernel, one launch per block (default: wn_gen_chain128_kernel, all blocks in one launch)
 //   36  = 1: the convs of stacks deeper than 1 on the padded rows GEMM (no shifted-plane form of wn_gemm_planes16s_kernel)
+//   37  = 1: dW of the head's first conv under the fold (a 1921-long contraction) on wn_wgrad_kernel (no split-K small products)
 // thread-local: a caller that switches kernel variants (the range guard's exact-fp32 retry, tools/ A/B runs, tests)
 // affects the launches of its own thread only
 static thread_local int g_wn_debug[64] = {0};

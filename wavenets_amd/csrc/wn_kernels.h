@@ -318,7 +318,7 @@ int wn_launch_sgemm_small(const float* A, int64_t sai, int64_t sak, const float*
                           int M, int N, int K, hipStream_t s);
 int wn_launch_sgemm_small_batched(const float* A, int64_t sai, int64_t sak, int64_t za, const float* B, int64_t sbk, int64_t sbj,
                                   int64_t zb, float* C, int ldc, int64_t zc, int M, int N, int K, int nz, const float* bias,
-                                  int act, hipStream_t s);
+                                  int act, hipStream_t s, int zk = 0);
 int wn_launch_skip_scatter(const float* Y, const float* colsum, int64_t ws_off0, int64_t ws_stride, int64_t bs_off0,
                            int64_t bs_stride, int64_t bf0_off, int N, int D, int S, int F0, float* grads, hipStream_t s);
 // dW, db of the input causal conv into the batched weight-gradient slab (wn_elem.hip)

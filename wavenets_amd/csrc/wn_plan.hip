@@ -2441,6 +2441,18 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       rc = wn_launch_sgemm_small(ws + L.mtot, F0, 1, wf0, 1, F0, ws + L.ytmp, p->S, nd1, p->S, F0, s);          // B[k = n][j = s]
       if (rc) return rc;
       // (a long-K product with a small output: the rows-contraction kernel splits K over workgroups)
+      // knob 37 = 1: wn_wgrad_kernel; default: split K in chunks of 128 on the small-product kernel, partial results in the
+      // (idle) slab, summed in chunk order
+      const int nzk = (nd1 + 127) / 128;
+      if (wn_debug_get(37) != 1 && (int64_t)nzk * p->S * F0 <= L.slab_floats) {
+        rc = wn_launch_sgemm_small_batched(ws + L.wsall, 1, p->S, (int64_t)128 * p->S, ws + L.mtot, F0, 1, (int64_t)128 * F0, slab, F0,
+                                           (int64_t)p->S * F0, p->S, F0, nd1, nzk, nullptr, 0, s, 128);
+        if (rc) return rc;
+        WnVecSumArgs v;
+        v.base = slab; v.off0 = 0; v.stride = (int64_t)p->S * F0; v.count = nzk; v.len = p->S * F0;
+        v.out = grads + p->tensors[c0.kernel_t].off;
+        rc = wn_launch_vecsum(v, s);
+      } else
       rc = wgrad(ws + L.wsall, p->S, p->S, 0, ws + L.mtot, F0, F0, 1, nd1, grads + p->tensors[c0.kernel_t].off, nullptr, nullptr,
                  slab, s);
       if (rc) return rc;
