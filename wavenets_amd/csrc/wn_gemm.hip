@@ -78,10 +78,11 @@ __global__ void wn_prep_one_kernel(WnPrepDesc d, const float* params, float* ws)
                (int64_t)gridDim.x * blockDim.x);
 }
 
+// gx = workgroups per descriptor (16 suits images of up to ~64 k elements; the folded skip path's 245 k-element image wants more)
 int wn_launch_prep_table(const WnPrepDesc* d_table, int n, const float* params, float* ws,
-                         hipStream_t s) {
+                         hipStream_t s, int gx) {
   if (n <= 0) return WN_OK;
-  dim3 grid(16, n);
+  dim3 grid(gx > 0 ? gx : 16, n);
   hipLaunchKernelGGL(wn_prep_table_kernel, grid, dim3(256), 0, s, d_table, params, ws);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;

@@ -21,7 +21,7 @@ struct WnPrepDesc {
   int32_t kind;      // 0: fp32 fragment image; 1: fp16 hi/lo split image for the 32x32x16 MFMA (q_off counts k-steps of 16)
 };
 int wn_launch_prep_table(const WnPrepDesc* d_table, int n, const float* params, float* ws,
-                         hipStream_t s);
+                         hipStream_t s, int gx = 16);
 int wn_launch_prep_one(WnPrepDesc d, const float* params, float* ws, hipStream_t s);
 // out[i] = sum_j src[offs[j] + i]   (sum of N bias vectors; offsets by value, N <= 64)
 struct WnVecSumArgs { const float* base; int64_t off0; int64_t stride; int32_t count; int32_t len; float* out; };

@@ -1572,7 +1572,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
                              p->tensors[p->finals[0].bias_t].off, ws + L.bias_sum, p->N, p->D, p->S, p->fold_F0, ws + L.vfold,
                              ws + L.bfold, ws + L.wsall, s);
     if (rc) return rc;
-    rc = wn_launch_prep_table(p->d_prep2, (int)p->prep2.size(), ws, fragbase, s);      // sources relative to the workspace
+    rc = wn_launch_prep_table(p->d_prep2, (int)p->prep2.size(), ws, fragbase, s, 64);  // sources relative to the workspace
     if (rc) return rc;
   }
   if (fp_prof) { (void)hipEventRecord(p->foldprep_ev[p->foldprep_used + 1], s); p->foldprep_used += 2; }
