@@ -59,6 +59,7 @@ def parse_args(argv=None):
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-strong-leg', action='store_true', help='skip the extra global-batch-64 measurement')
   ap.add_argument('--no-generation', action='store_true', help='skip the generation-speed leg (N = 1 only)')
+  ap.add_argument('--no-dp-leg', action='store_true', help='skip the world-size-1 RCCL data-parallel leg (N = 1 only)')
   ap.add_argument('--no-other-configs', action='store_true', help='skip the other BASELINE configs (N = 1 only)')
   ap.add_argument('--cpu-budget', type=float, default=20.0)
   return ap.parse_args(argv)
@@ -386,7 +387,36 @@ def main():
       model.optimizer.apply_gradients(model)
   sync()
 
+  # N = 1: the DATA-PARALLEL form of the same step on the real backend -- a process group of one rank on "nccl" (= RCCL):
+  # dp.allreduce_bucket then runs librccl's all-reduce on the gradient bucket, and train_step takes its data-parallel
+  # path (scalars out of the all-reduced bucket tail through a pinned copy + event; ONE collective per step) instead of
+  # the single-replica early read.  `dp_mode.ms_per_step` is what that path costs against the headline.
+  dp_mode = None
+  if world == 1 and not args.no_dp_leg:
+    try:
+      import socket
+      sk = socket.socket()
+      sk.bind(('127.0.0.1', 0))
+      port = sk.getsockname()[1]
+      sk.close()
+      dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+      nd = max(3, min(args.steps, 20))
+      dp_mode = {'backend': 'nccl (RCCL)', 'world_size': 1}
+      for key, early in (('one_collective_tail_read', None), ('early_read_second_small_collective', True)):
+        model.early_logs = early
+        dtd, _, _ = timed_steps(model, x, nd, 3)
+        dp_mode[key] = {'ms_per_step': dtd / nd * 1e3, 'steps': nd, 'vs_headline': (dtd / nd * 1e3) / ms_per_step}
+      dp_mode['ms_per_step'] = dp_mode['one_collective_tail_read']['ms_per_step']     # the default data-parallel path
+      dp_mode['guard_trips'] = model.train_guard_trips
+    except Exception as e:                                 # report, do not lose the headline
+      dp_mode = {'error': f'{type(e).__name__}: {e}'[:300]}
+    finally:
+      model.early_logs = None
+      if dist.is_initialized():
+        dist.destroy_process_group()
+
   # the same step with the exact-fp32 MFMA kernels (debug knob 1), reported beside the default
+  guard_trips = model.train_guard_trips                   # steps of this run repeated in exact fp32 by the range guard
   L.wn_debug_set(1, 1)
   nf = max(2, min(args.steps // 3, 10))
   dt_fp32, _, _ = timed_steps(model, x, nf, 1)
@@ -424,7 +454,9 @@ def main():
         traffic = float(row['total_bytes_corrected'])
     for row in _profile_rows('r0*_train_pmc_sq.csv'):
       if 'wn_layer_fwd_f16_kernel' in row['kernel']:
-        mfma_busy = float(row['mfma_busy_per_wave_cycle'])
+        # busy share of the chip's 1024 matrix pipes over the kernel's duration (tools/summarise_profiles.py); the round-3
+        # files carry MFMA busy cycles per wave quad-cycle instead: x 2 waves per SIMD for the pipe's share
+        mfma_busy = float(row['mfma_pipe_util']) if 'mfma_pipe_util' in row else 2.0 * float(row['mfma_busy_per_wave_cycle'])
     R, S = CFG2['channels'], CFG2['skip_channels']
     bytes_layer = 4.0 * B * T * (2 * R + S)          # read x, write x_out, write skip
     stack_bytes = nblk * bytes_layer
@@ -436,11 +468,16 @@ def main():
         'metric': 'audio samples/sec (training step, 16 kHz mu-law)',
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32 (fp16 hi|lo split operands, fp32 accumulate)', 'data': 'synthetic',
+        'ms_per_step_exact_fp32_mfma': dt_fp32 * 1e3, 'value_exact_fp32_mfma': world * B * T / dt_fp32,
+        'range_guard_trips': guard_trips,
         'ms_per_step_median': pct(0.5), 'ms_per_step_p10': pct(0.1), 'ms_per_step_p90': pct(0.9),
         'math': 'fp32 tensors; contractions as fp16 hi/lo split, 3 products on v_mfma_f32_32x32x16_f16 with fp32 '
                 'accumulate (|err| <= 6e-7 on O(1) results, parity-tested at 1e-4); exact-fp32 MFMA selectable',
-        'exact_fp32_mfma': {'ms_per_step': dt_fp32 * 1e3, 'value': world * B * T / dt_fp32},
+        'exact_fp32_mfma': {'ms_per_step': dt_fp32 * 1e3, 'value': world * B * T / dt_fp32,
+                            'note': 'the same step with v_mfma_f32_32x32x2_f32 contractions (no operand split): what a step '
+                                    'costs when the range guard repeats it; range_guard_trips counts such repeats in the timed run'},
+        'dp_mode': dp_mode,
         'phases_ms': phases, 'kernel_families': kernel_families,
         'config': {'workload': 'configs[1]: 30-layer (3x10) mu-law-256 WaveNet, 64 residual / 256 skip ch, '
                                f'head [128,256], batch {B}x{T} per GPU, full train step '
@@ -462,7 +499,9 @@ def main():
                                             'launches_timed': n_l, 'counter_bytes_per_launch': traffic,
                                             'counter_GBps': kern_gbs,
                                             'counter_frac_of_peak': (kern_gbs / HBM_PEAK_GBS) if kern_gbs else None,
-                                            'mfma_busy_per_wave_cycle': mfma_busy},
+                                            'mfma_pipe_util': mfma_busy,
+                                            'mfma_pipe_util_note': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 matrix pipes x kernel '
+                                                                   'cycles); the kernel runs 2 waves per SIMD (8-wave workgroup per CU)'},
                      'note': 'measured in extra untimed steps after the timed region; traffic = HBM bytes per launch of the '
                              'fused block kernel (profiles/, FETCH x2 + WRITE); it writes x_out, z and the saved sigmoid -- '
                              'the skip tensors of the algorithmic signature are consumed inside the folded contraction, which '

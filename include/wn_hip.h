@@ -194,10 +194,12 @@ int wn_generate(wn_plan* p, const float* params, const float* window, const floa
                 int32_t length, int32_t deterministic, int32_t queued, uint64_t seed, float* out,
                 float* workspace, int64_t ws_floats, void* stream);
 int64_t wn_generate_workspace_floats(const wn_plan* p, int32_t B, int32_t queued);
-/* float offset, inside the caller's generation workspace, of the call's range-guard slot: after wn_generate (stream
- * synchronised) it holds the largest |activation| any split-precision kernel of the call was fed (priming pass, per-step
- * blocks, the fused chain kernel's residual stream and folded skip sum); at or beyond wn_range_limit() the samples are
- * not valid and the call is to be repeated with the exact-fp32 kernels (wn_debug_set(1, 1)). */
+/* float offset, inside the caller's generation workspace, of the call's range-guard slot.  After wn_generate (stream
+ * synchronised) the float is >= wn_range_limit() if and only if some split-precision kernel of the call was fed an
+ * |activation| at or beyond that limit: the priming pass (residual stream, skip sum, head activations), and in EVERY
+ * queued step the residual stream and folded skip sum of the chain kernels, the per-block kernels, the skip contraction
+ * and the hidden head activations.  (Below the limit it holds the priming pass's largest magnitude; the per-step kernels
+ * only ever raise it past the limit.)  A tripped call is to be repeated with the exact-fp32 kernels (wn_debug_set(1, 1)). */
 int64_t wn_generate_guard_slot(const wn_plan* p, int32_t B, int32_t queued);
 
 /* ---- WaveNetLayer.call, src/layers.py:178-224, standalone block ----
@@ -244,6 +246,11 @@ int wn_plan_arm_step_sample(wn_plan* plan, float* sample_out, int32_t determinis
  * backward pass and the weight gradients of THAT forward pass (same arguments, same workspace), 3 = both (default).  A
  * host driver uses the gap to queue its read-back of loss / metrics 4 ms before the step ends. */
 int wn_plan_set_train_phases(wn_plan* plan, int32_t phases);
+/* tf.keras.metrics.MeanSquaredError(y_true, sample) of one step (train.py:227, src/model.py:338-346) as a device scalar:
+ * out[0] = scale * sum_i (a[i] - b[i])^2 in double accumulation; scale = 1 / (n * replicas) makes the SUM over the
+ * replicas the metric's mean.  scratch: >= 2048 floats of the caller's. */
+int wn_sum_squared_error(const float* a, const float* b, int64_t n, float scale, float* out, float* scratch,
+                         void* stream);
 /* WaveNet.sample_waveform(pred, deterministic), src/model.py:393-503: (rows,C) -> (rows) */
 int wn_sample_waveform(int32_t head, const float* pred, int64_t rows, int32_t C,
                        int32_t num_mixtures, int32_t bits, int32_t deterministic, uint64_t seed,

@@ -106,6 +106,54 @@ def test_two_rank_train_step_equals_single_process(tmp_path, backend, net):
     assert abs(logs['reg_loss'] - r0['logs']['reg_loss']) < 1e-6 * max(1.0, abs(logs['reg_loss']))
 
 
+def _nccl1_worker(rank, port, out_dir, early):
+  """RCCL for real on a one-GPU box: a process group of ONE rank on backend "nccl" (train.py:203 with one visible device).
+  dist.all_reduce then runs through librccl -- communicator creation bound to the device (device_id), the bucket + tail
+  layout, the stream hand-over between RCCL's stream and the launch stream -- with a world of one."""
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  torch.cuda.set_device(0)
+  dev = torch.device('cuda', 0)
+  dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+  from wavenets_amd import WaveNet, dp
+  assert dp.initialized() and dp.world_size() == 1 and dist.get_backend() == 'nccl'
+  # a bare collective first: the communicator is created here, on this device
+  probe = torch.arange(8, dtype=torch.float32, device=dev)
+  dp.allreduce_bucket(probe)
+  assert torch.equal(probe.cpu(), torch.arange(8, dtype=torch.float32))
+  model = WaveNet(**KW_CONFIGS1, device=dev, seed=7)
+  model.early_logs = early                                       # None: automatic = the one-collective tail path
+  x = _data('configs1').to(dev)
+  logs = _run_steps(model, x)
+  test_logs = model.test_step(x)
+  torch.cuda.synchronize()
+  torch.save({'params': model.flat_params.data.cpu(), 'logs': logs, 'test_logs': test_logs,
+              'trips': (model.train_guard_trips, model.test_guard_trips)}, os.path.join(out_dir, 'nccl1.pt'))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('early', [None, True])
+def test_nccl_world_size_one_drives_train_and_test_step(tmp_path, early):
+  """BASELINE configs[2]'s exchange on the real backend as far as one GPU allows: WaveNet.train_step + test_step of the
+  exact configs[1] network through dp.allreduce_bucket over RCCL (world size 1).  The data-parallel step path -- scalars
+  from the all-reduced bucket tail through the pinned copy + event, or (early = True) a second tiny collective between
+  forward and backward -- must reproduce the single-process step bit for bit: same kernels, same gradients, the reduce
+  of one replica is the identity."""
+  from wavenets_amd import WaveNet
+  mp.spawn(_nccl1_worker, args=(_free_port(), str(tmp_path), early), nprocs=1, join=True)
+  r = torch.load(tmp_path / 'nccl1.pt')
+  dev = torch.device('cuda', 0)
+  single = WaveNet(**KW_CONFIGS1, device=dev, seed=7)
+  x = _data('configs1').to(dev)
+  logs = _run_steps(single, x)
+  test_logs = single.test_step(x)
+  assert torch.equal(single.flat_params.data.cpu(), r['params'])
+  assert logs == r['logs'] and test_logs == r['test_logs'], (logs, r['logs'], test_logs, r['test_logs'])
+  assert r['trips'] == (0, 0)
+
+
 def test_two_rank_dropout_masks_differ_per_replica(tmp_path):
   """MirroredStrategy draws an independent Dropout mask on every replica: the mask counter folds the rank in
   (call_index * world + rank + 1).  Replicas must still agree bit for bit after the reduce."""

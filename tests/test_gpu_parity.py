@@ -603,6 +603,31 @@ def test_generation_range_guard_repeats_in_exact_fp32(name, queued):
   assert 0.0 < v < 100.0 and getattr(model2, 'generation_guard_trips', 0) == 0
 
 
+@pytest.mark.parametrize('name', ['cat_small_fused', 'cat_r64', 'cat_r128'])
+def test_generation_range_guard_catches_an_overflow_that_only_a_generated_sample_causes(name):
+  """The priming pass stays in range (an all-zero window: the residual stream is the input conv's bias), but the first
+  GENERATED sample is non-zero and a huge input-conv kernel turns it into a residual stream of ~1e4..1e5 from queued step 1
+  on -- steps the chain kernel used to publish only every 32nd time.  The guard slot must be raised in that very step
+  and the call repeated in exact fp32 (src/model.py:296-305)."""
+  kw = dict(MODEL_CASES[name])
+  ocfg, params, model = make_pair(seed=11, bias_range=0.1, **kw)
+  names = model.variable_names
+  ws = [p.clone() for p in params]
+  ck = names.index('causal/kernel')
+  ws[ck] = torch.full_like(ws[ck], 6.0e5)             # (k, 1, R): samples are multiples of 1/128 -> |H[0]| >= 4.7e3 * k
+  model.set_weights([w.numpy() for w in ws])
+  w0 = torch.zeros(2, model.receptive_field, 1, device=dev())
+  n = 7                                               # steps 1..6 are queued steps; none is a multiple of 32, 6 is the last
+  with model.exact_fp32():
+    ref = model.generate(n, sample=w0, deterministic=True, use_queues=True)
+  assert model.generation_guard_trips == 0
+  if float(ref[:, :n - 2].abs().max()) < 0.06:
+    pytest.skip('the first samples of this seed are (almost) zero: no overflow to provoke')
+  out = model.generate(n, sample=w0, deterministic=True, use_queues=True)
+  assert model.generation_guard_trips == 1
+  assert torch.isfinite(out).all() and torch.equal(out, ref)
+
+
 def test_generate_errors():
   from wavenets_amd import WaveNet
   m = WaveNet(blocks=2, channels=32, dilation_bound=4, final_layers_channels=[], conditioning='global',

@@ -3,10 +3,12 @@
 #   kernel trace of `python bench.py` (configs[1] headline), and for configs[1] (tools/prof_train.py) and configs[3]
 #   (tools/prof_cfg4.py): kernel trace + SEPARATE --pmc passes for FETCH_SIZE, WRITE_SIZE and the SQ counters
 #   (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no --pmc together with trace domains other than
-#   --kernel-trace).  Outputs under gpurun_out/prof_r03/; tools/summarise_r03.py turns them into profiles/r03_*.csv.
+#   --kernel-trace).  Outputs under gpurun_out/prof_<tag>/; tools/summarise_profiles.py turns them into
+#   gpurun_out/prof_<tag>_summary/<tag>_*.csv, which are then copied into profiles/.   usage: collect_profiles.sh [tag]
 set -o pipefail
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/prof_r03
+OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, program...
@@ -23,6 +25,8 @@ for cfg in train cfg4; do
   run ${cfg}_sq --kernel-trace --pmc $SQ -d $OUT/${cfg}_sq -o $cfg -- python3 $prog > $OUT/${cfg}_sq.log 2>&1
 done
 # summaries only travel back (the raw databases and counter tables are tens of MB)
-python3 $ROOT/tools/summarise_r03.py r03 $ROOT/gpurun_out/prof_r03_summary > $OUT/../prof_r03_summary.log 2>&1
+# (the raw outputs are deleted only after the summariser succeeded: a failed summary must not cost a second profiling run)
+python3 $ROOT/tools/summarise_profiles.py $TAG $ROOT/gpurun_out/prof_${TAG}_summary > $OUT/../prof_${TAG}_summary.log 2>&1 \
+  || { echo "FAILED summarise (raw outputs kept in $OUT)"; tail -20 $OUT/../prof_${TAG}_summary.log; exit 1; }
 rm -rf $OUT
-ls -la $ROOT/gpurun_out/prof_r03_summary
+ls -la $ROOT/gpurun_out/prof_${TAG}_summary

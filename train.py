@@ -135,6 +135,7 @@ def main():
       metric.reset_state()
     t0 = time.time()
     stop = False
+    trips0 = model.train_guard_trips
     for i in range(n_batches):
       idx = perm[i * config['batch_size']:(i + 1) * config['batch_size']][rank * per_rank:(rank + 1) * per_rank]
       idx = idx.to(dev)
@@ -147,6 +148,10 @@ def main():
     if rank == 0:
       sps = n_batches * config['batch_size'] * L / max(time.time() - t0, 1e-9)
       extra = ''.join(f' - {k}: {v:.4f}' for k, v in logs.items() if k != 'loss')   # the compiled metrics, as Keras logs them
+      # steps that left the fp16 range of the split-precision kernels and were repeated in exact fp32 (each costs a second,
+      # ~2.7x slower step): shown only when there were any
+      trips = model.train_guard_trips - trips0
+      extra += f' - exact-fp32 repeats: {trips}' if trips else ''
       print(f'Epoch {epoch + 1}/{config["epochs"]} - loss: {loss:.4f}{extra} - lr: {opt.learning_rate:g} - {sps:,.0f} samples/s')
       if loss < best:                                               # ModelCheckpoint(save_best_only, monitor='loss')
         best = loss

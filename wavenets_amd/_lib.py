@@ -111,6 +111,7 @@ _SIGS = {
     'wn_loss_fn': (C.c_int, [C.c_int32, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'wn_plan_arm_step_sample': (C.c_int, [_P, _P, C.c_int32, C.c_uint64, C.c_uint64]),
     'wn_plan_set_train_phases': (C.c_int, [_P, C.c_int32]),
+    'wn_sum_squared_error': (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P, _P]),
     'wn_sample_waveform': (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_uint64, C.c_uint64, _P, _P]),
 }

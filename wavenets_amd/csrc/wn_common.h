@@ -150,5 +150,16 @@ __device__ __forceinline__ float wn_wave_absmax_bits(float wmax) {
 // forward activations at or beyond this magnitude trip the range guard of the split-precision mode (fp16 max 65504)
 #define WN_RANGE_LIMIT 30000.0f
 
+// Guard publish of the per-sample generation kernels: a lane raises the slot only when ITS running max-abs reached the limit
+// (or is inf / NaN) -- no wave reduction and no read of the slot, so it can run every step; below the limit the slot keeps
+// whatever the priming pass left there.
+__device__ __forceinline__ void wn_guard_publish_over(float* slot, float wmax) {
+  const unsigned m = __float_as_uint(wmax);
+  if (m >= __float_as_uint(WN_RANGE_LIMIT)) {
+    const float v = __uint_as_float(m);
+    atomicMax(reinterpret_cast<int*>(slot), __float_as_int(v < 3.0e38f ? v : 3.0e38f));
+  }
+}
+
 void wn_set_error(const char* fmt, ...);
 int wn_debug_get(int key);   // tuning knobs (wn_error.cpp): 0 = layer-forward kernel variant

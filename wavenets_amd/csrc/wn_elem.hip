@@ -546,6 +546,32 @@ int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scr
   return WN_OK;
 }
 
+// out[0] = scale * sum((a - b)^2): tf.keras.metrics.MeanSquaredError(y_true, sample) of a step (src/model.py:346,
+// train.py:227) with scale = 1 / (n * replicas); same two-stage double accumulation as wn_launch_sum
+__global__ void wn_sqdiff_stage1(const float* a, const float* b, int64_t n, double* scratch) {
+  __shared__ double sm[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    acc += (double)(d * d);
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scratch[blockIdx.x] = sm[0];
+}
+int wn_launch_sqdiff_sum(const float* a, const float* b, int64_t n, float scale, float* out, float* scratch, hipStream_t s) {
+  int nb = wn_blocks(n, 256, 1024);
+  hipLaunchKernelGGL(wn_sqdiff_stage1, dim3(nb), dim3(256), 0, s, a, b, n, reinterpret_cast<double*>(scratch));
+  hipLaunchKernelGGL(wn_sum_stage2, dim3(1), dim3(256), 0, s, reinterpret_cast<const double*>(scratch), nb, scale, out);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // samplers
 // (queued generation: the sample also goes to its place in the output rows and into the network's input ring -- the

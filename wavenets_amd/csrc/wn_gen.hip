@@ -771,10 +771,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       for (int rq = 0; rq < 4; ++rq)
         *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{x[4 * rq + 0], x[4 * rq + 1], x[4 * rq + 2], x[4 * rq + 3]};
     }
-    if (a.guard) {                                    // one read (and rarely one atomic) per wave and step
-      xm = wn_wave_absmax_bits(live ? xm : 0.f);
-      if (lane == 0) wn_absmax_publish_any(a.guard, xm);
-    }
+    if (a.guard) wn_guard_publish_over(a.guard, live ? xm : 0.f);     // every step; an atomic only beyond the limit
   } else {
     // ================= skip waves: acc_t += W_{s,b}^T z for column tiles t0 = 2 sw and t1 = 2 sw + 1 =================
     // Two register sets per tile (set = block parity).  Tile t0 of block b runs between barriers (2) and (3) of block b,
@@ -903,10 +900,7 @@ __global__ __launch_bounds__(64 * (2 * D32 + R32 + 4)) void wn_gen_chain3_kernel
       put(acc0, t0);
       if (has1) put(acc1, t1);
     }
-    if (a.guard) {                                    // the head casts this row to fp16 hi | lo
-      sm = wn_wave_absmax_bits(sm);
-      if (lane == 0) wn_absmax_publish_any(a.guard, sm);
-    }
+    if (a.guard) wn_guard_publish_over(a.guard, sm);  // the head casts this row to fp16 hi | lo
   }
 }
 
@@ -991,7 +985,13 @@ __device__ __forceinline__ void gn_head_body(const WnGenHeadArgs& a, int tile, u
             *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{v[4 * rq + 0], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
         }
       } else {
-        // this tile = k-steps 2 wave, 2 wave + 1 of the next layer
+        // this tile = k-steps 2 wave, 2 wave + 1 of the next layer (cast to fp16 hi | lo unscaled: range guard)
+        if (a.guard) {
+          float vm = 0.f;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) vm = wn_absmax_acc(vm, v[4 * rq + 0], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]);
+          wn_guard_publish_over(a.guard, live ? vm : 0.f);
+        }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const f32x4 q0 = {v[8 * hf + 0], v[8 * hf + 1], v[8 * hf + 2], v[8 * hf + 3]};

@@ -286,6 +286,7 @@ struct WnGenHeadArgs {
   uint64_t seed, offset;           // Philox key / counter word of a stochastic draw
   float* samp;                     // [B] samples (or null)
   WnEmit em;                       // output rows / network input slot
+  float* guard;                    // range guard of the generate call (hidden activations are cast to fp16 hi | lo), or null
 };
 int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s);
 int wn_gen_blocks_supported(int R, int D, int KS);
@@ -355,6 +356,7 @@ int wn_launch_cat_loss_probs(const float* probs, const int32_t* target, int64_t 
 int wn_launch_mix_loss(const float* pred, const float* y, int64_t rows, int M, int bits, int kind,
                        float gscale, float* loss_rows, float* g_pred, float* absmax_out, hipStream_t s);
 int wn_launch_sum(const float* v, int64_t n, float scale, float* out, float* scratch, hipStream_t s);
+int wn_launch_sqdiff_sum(const float* a, const float* b, int64_t n, float scale, float* out, float* scratch, hipStream_t s);
 // deterministic samplers: categorical argmax -> left bin edge; mixtures -> clipped mean
 int wn_launch_sample_det_emit(const float* pred, int64_t rows, int C, int M, int bits, float* out, WnEmit em, hipStream_t s);
 int wn_launch_sample_rand_emit(const float* pred, int64_t rows, int C, int M, int bits, int kind, uint64_t seed, uint64_t offset,

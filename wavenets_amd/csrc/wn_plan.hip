@@ -1702,7 +1702,9 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     // a = act(sum_b V(b)^T z_b + b'): the skip sum and the head's first conv in ONE contraction with F0 output columns
     const ConvInfo& c0 = p->finals[0];
     // streamed kernel, second form (wn_gemm16s.hip: bit-identical results; knob 31 = 1: wn_gemm_rows16_kernel)
-    if (wn_debug_get(31) != 1 && p->Dp == p->D && wn_gemm_planes16s_supported(c0.cout, p->D, p->N, p->Dp, c0.cout)) {
+    // (the streamed form indexes rows with 32-bit byte offsets: beyond 4 GiB per plane the rows GEMM takes over)
+    if (wn_debug_get(31) != 1 && p->Dp == p->D && wn_gemm_planes16s_supported(c0.cout, p->D, p->N, p->Dp, c0.cout) &&
+        (int64_t)rows * p->Dp * 4 < ((int64_t)1 << 32) && (int64_t)rows * c0.cout * 4 < ((int64_t)1 << 32)) {
       WnGemmPlanesArgs ga;
       memset(&ga, 0, sizeof(ga));
       ga.z = ws + L.Z; ga.plane_stride = rows * p->Dp; ga.ld = p->Dp; ga.plane_k = p->D; ga.nplanes = p->N;
@@ -2271,7 +2273,9 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     const bool pairk = fold && p->N >= 2 && p->drop_rate == 0.f && p->c.use_residual && (p->c.cond_inputs == 0 || cond_batched) && !have_gzs &&
                        (wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) || wn_bwd_s128_supported(p->R, p->D, p->KS, p->fold_F0)) &&
                        p->Dp == p->D && wn_debug_get(22) != 1 &&
-                       wn_debug_get(15) != 1;
+                       wn_debug_get(15) != 1 &&
+                       // (the streamed R = 128 pair kernel indexes with 32-bit byte offsets: the two-launch chain takes over beyond)
+                       (p->R != 128 || (int64_t)rows * 2 * p->D * 4 < ((int64_t)1 << 32));
     for (int b = p->N - 1; b >= 0; --b) {
       BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
       deep16_ptrs(p, b, fragbase, k);
@@ -2913,10 +2917,9 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
         ga.skiprow_off = G.skiprow; ga.skip_ld = skipw; ga.skip_tiles = skipw / 32;
         ga.skip_act = gfold ? p->c.activation : WN_ACT_LINEAR;
       }
-      // the chain kernel publishes its running max-abs every 32nd step and at the last one: an overflow of the fp16
-      // range turns into inf / NaN in the residual stream and the rings and stays there, so a later check still sees it
-      // (publishing every step costs ~2 us of the 62 us step)
-      ga.guard = (step % 32 == 0 || step == length - 1) ? gguard : nullptr;
+      // the chain kernel raises the guard slot in EVERY step, but only from lanes whose own running max-abs reached the
+      // limit (wn_guard_publish_over: no wave reduction, no read of the slot)
+      ga.guard = gguard;
       ga.zrow_off = G.Zrow; ga.hrow_off = p->c.use_skip ? -1 : G.hrow0; ga.tau = tau;
       ga.B = B; ga.nblocks = p->N; ga.residual = p->c.use_residual;
       rc = wn_launch_gen_blocks(ga, p->R, p->KS, (pre_in_head && step > 1) ? 2 : 3, s);
@@ -2997,7 +3000,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       rc = Gemm(1, B, skipw, ceil32(skipw)).seg_planes(Zrow, p->Dp, (int64_t)B * p->Dp, p->N * p->Dp, gfold ? nullptr : fragbase + p->frag_skipF)
                .w16(skip_img >= 0 ? fragbase + skip_img : nullptr)
                .bias(pws + (gfold ? L.bfold : L.bias_sum)).act(gfold ? p->c.activation : WN_ACT_LINEAR)
-               .run(workspace + G.skiprow, skipw, s);
+               .absmax_fwd(gguard).run(workspace + G.skiprow, skipw, s);
       if (rc) return rc;
       hin = workspace + G.skiprow;
     } else {
@@ -3010,6 +3013,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       memset(&ha, 0, sizeof(ha));
       ha.params = params; ha.ws = workspace; ha.in_off = hin - workspace; ha.in_ld = hc; ha.out_off = G.last;
       ha.nlayers = (int)(p->finals.size() - first_final); ha.B = B;
+      ha.guard = gguard;
       for (size_t i = first_final; i < p->finals.size(); ++i) {
         const ConvInfo& c = p->finals[i];
         const size_t l = i - first_final;
@@ -3044,7 +3048,8 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       float* dst = lastl ? last : workspace + G.HArow[i];
       rc = Gemm(1, B, c.cout, ceil32(c.cout)).seg(hin, hc, hc, 0, fragbase + c.fragF)
                .w16(c.frag16 >= 0 ? fragbase + c.frag16 : nullptr)
-               .bias(params + p->tensors[c.bias_t].off).act(lastl ? WN_ACT_LINEAR : p->c.activation).run(dst, c.cout, s);
+               .bias(params + p->tensors[c.bias_t].off).act(lastl ? WN_ACT_LINEAR : p->c.activation)
+               .absmax_fwd(lastl ? nullptr : gguard).run(dst, c.cout, s);
       if (rc) return rc;
       hin = dst; hc = c.cout;
     }
@@ -3335,6 +3340,11 @@ extern "C" int wn_loss_fn(int32_t head, const void* target, const float* pred, i
                               1.0f, loss_rows, nullptr, nullptr, s);
   wn_set_error("Loss %d not implemented.", head);
   return WN_E_UNSUPPORTED;
+}
+extern "C" int wn_sum_squared_error(const float* a, const float* b, int64_t n, float scale, float* out, float* scratch,
+                                    void* stream) {
+  if (!a || !b || !out || !scratch || n < 1) { wn_set_error("sum_squared_error: bad arguments"); return WN_E_INVALID; }
+  return wn_launch_sqdiff_sum(a, b, n, scale, out, scratch, (hipStream_t)stream);
 }
 extern "C" int wn_plan_arm_step_sample(wn_plan* p, float* sample_out, int32_t deterministic, uint64_t seed, uint64_t offset) {
   if (!p) { wn_set_error("arm_step_sample: null plan"); return WN_E_INVALID; }

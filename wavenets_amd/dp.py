@@ -14,6 +14,12 @@ import torch
 import torch.distributed as dist
 
 
+def initialized() -> bool:
+  """A process group exists (world size 1 included): the data-parallel step then goes through the collective backend --
+  RCCL for backend "nccl" -- even when this process is the only replica."""
+  return dist.is_available() and dist.is_initialized()
+
+
 def world_size() -> int:
   return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -35,7 +41,7 @@ def allreduce_gradients(flat_grads: torch.Tensor, loss: torch.Tensor, group=None
 
   loss[0] holds this replica's ``sum_local(l) / B_global`` -> summed gives the global loss;
   loss[1] holds ``l2 / n_replicas`` on every replica -> summed gives the full penalty."""
-  if world_size() == 1:
+  if not initialized():
     return
   dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
   dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
@@ -43,7 +49,8 @@ def allreduce_gradients(flat_grads: torch.Tensor, loss: torch.Tensor, group=None
 
 def allreduce_bucket(bucket: torch.Tensor, group=None) -> None:
   """The same exchange as ``allreduce_gradients`` when the {loss, reg_loss} pair lives right behind the flat
-  gradient in one buffer (``WaveNet._grad_bucket``): a single collective per step."""
-  if world_size() == 1:
+  gradient in one buffer (``WaveNet._grad_bucket``): a single collective per step.  Without a process group: nothing;
+  with one -- of any size, 1 included -- the backend's all-reduce runs."""
+  if not initialized():
     return
   dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)

@@ -44,19 +44,30 @@ class MeanSquaredError:
   name = 'mean_squared_error'
 
   def __init__(self):
+    self._scratch = None
     self.reset_state()
 
   def reset_state(self):
     self.total, self.count = 0.0, 0
 
   def update_state(self, y_true, y_pred):
-    self.total += float(torch.mean((y_true - y_pred) ** 2))
+    self.total += float(self.update_state_device(y_true, y_pred))
     self.count += 1
 
-  # two-phase form used by train_step / test_step: the reduction is queued behind the step's kernels and its
-  # value comes back in the step's single device-to-host read (no second synchronisation)
-  def update_state_device(self, y_true, y_pred):
-    return torch.mean((y_true - y_pred) ** 2).reshape(1)
+  # two-phase form used by train_step / test_step: the reduction is queued behind the step's kernels (one library launch
+  # pair, no torch arithmetic) and its value comes back in the step's single device-to-host read.  ``out``: a one-float
+  # device view to write into (the gradient bucket's tail in a training step); ``scale`` = 1 / replicas makes the SUM
+  # over the replicas the mean Keras reports.
+  def update_state_device(self, y_true, y_pred, out=None, scale=1.0):
+    n = y_true.numel()
+    if out is None:
+      out = torch.empty(1, dtype=torch.float32, device=y_true.device)
+    if self._scratch is None or self._scratch.device != y_true.device:
+      self._scratch = torch.empty(2048, dtype=torch.float32, device=y_true.device)
+    _lib.check(_lib.lib().wn_sum_squared_error(_lib.ptr(y_true.contiguous()), _lib.ptr(y_pred.contiguous()), n,
+                                               float(scale) / n, _lib.ptr(out), _lib.ptr(self._scratch),
+                                               _lib.stream_ptr()))
+    return out
 
   def commit(self, value):
     self.total += float(value)
@@ -84,6 +95,7 @@ class _Mean:
 
 class WaveNet(torch.nn.Module):
   """WaveNet model class (src/model.py:11-556)."""
+  _TAIL_METRICS = 5      # device-reduced metric slots behind {loss, reg_loss, range_flag} in the gradient bucket
 
   def __init__(self,
                kernel_size: int = 2,
@@ -133,6 +145,11 @@ class WaveNet(torch.nn.Module):
     self.loss_tracker = _Mean('loss')
     self.reg_loss = _Mean('reg_loss') if self.regularization else None
     self._sample_calls = 0
+    # steps / evaluation passes / generate calls that left the range of the split-precision kernels and were repeated
+    # in exact fp32 (each costs a second, slower pass; train.py logs them per epoch)
+    self.train_guard_trips = 0
+    self.test_guard_trips = 0
+    self.generation_guard_trips = 0
     # None = automatic: a single replica reads its step scalars back between forward and backward; data-parallel replicas
     # take them from the gradient bucket's tail after the ONE all-reduce of the step (no second collective per step)
     self.early_logs = None
@@ -230,8 +247,10 @@ class WaveNet(torch.nn.Module):
         cnt = int(np.prod(shp))
         flat[o:o + cnt] = (torch.rand(cnt, generator=g) * 2 - 1) * lim
     self.flat_params = torch.nn.Parameter(flat.to(self._device), requires_grad=False)
-    # gradient bucket = [flat gradient | loss, reg_loss, range_flag]: the data-parallel exchange is ONE all-reduce
-    self._grad_bucket = torch.zeros(self.flat_params.numel() + 3, dtype=torch.float32, device=self._device)
+    # gradient bucket = [flat gradient | loss, reg_loss, range_flag, device-reduced metrics]: the data-parallel exchange
+    # is ONE all-reduce
+    self._grad_bucket = torch.zeros(self.flat_params.numel() + 3 + self._TAIL_METRICS, dtype=torch.float32,
+                                    device=self._device)
     self.flat_grads = self._grad_bucket[:self.flat_params.numel()]
     self.built = True
     if self.optimizer is not None:
@@ -359,19 +378,22 @@ class WaveNet(torch.nn.Module):
                     _lib.ptr(out) if want_probs else None, None if want_probs else _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                     _lib.stream_ptr()))
     run()
-    self._last_fwd = (ws, B, T, training)
-    if self.range_check and L.wn_debug_value(1) != 1 and self._range_tripped(ws, B, T, training):
+    # the pass's guard float, copied out of the shared workspace on the stream (a later pass on the same workspace -- another
+    # call, a test_step -- overwrites the slot; this one-float copy is what range_tripped_last_forward() reads)
+    slot = L.wn_plan_range_slot(self._plan, B, T, int(training))
+    self._last_fwd = (ws[slot:slot + 1].clone(), training)
+    if self.range_check and L.wn_debug_value(1) != 1 and self._guard_over(*self._last_fwd):
       with self.exact_fp32():
         run()
     return out
 
   def range_tripped_last_forward(self) -> bool:
-    """Deferred form of the guard check of call() / logits() (range_check = False): did the last forward pass leave the
-    range of the split-precision kernels?  (Repeat it inside `with model.exact_fp32():` if so.)"""
+    """Deferred form of the guard check of call() / logits() (range_check = False): did the last call() / logits() pass
+    leave the range of the split-precision kernels?  (Repeat it inside `with model.exact_fp32():` if so.  With
+    range_check = False nothing else checks: an unchecked pass may hold inf / NaN.)"""
     if self._last_fwd is None:
       return False
-    ws, B, T, training = self._last_fwd
-    return bool(self._range_tripped(ws, B, T, training))
+    return bool(self._guard_over(*self._last_fwd))
 
   def forward(self, inputs, training=False):
     return self.call(inputs, training=training)
@@ -403,15 +425,6 @@ class WaveNet(torch.nn.Module):
     _lib.check(_lib.lib().wn_debug_ws_region(self._plan, B, T, what, idx, C.byref(off), C.byref(ln)))
     return self._ws['train'][off.value:off.value + ln.value]
 
-  def _replica_mean(self, values):
-    """Metric values are means over this replica's rows; Keras aggregates them over the replicas (equal shares)."""
-    world = self._world()
-    if world > 1:
-      import torch.distributed as dist
-      dist.all_reduce(values, op=dist.ReduceOp.SUM)
-      values = values / world
-    return values
-
   def exact_fp32(self):
     """Context manager: the calling thread's launches use the exact-fp32 MFMA kernels (no fp16 hi|lo operand split)."""
     import contextlib
@@ -427,13 +440,11 @@ class WaveNet(torch.nn.Module):
         L.wn_debug_set(1, prev)
     return _cm()
 
-  def _range_tripped(self, ws, B, T, training):
-    """Reads the forward range-guard slot of the pass just enqueued on ``ws`` (one host sync)."""
-    L = _lib.lib()
-    slot = L.wn_plan_range_slot(self._plan, B, T, int(training))
-    m = float(ws[slot])
+  def _guard_over(self, guard, training):
+    """Reads a pass's copied range-guard float (one host sync) against the limit of the split-precision kernels."""
+    m = float(guard)
     # with dropout the split kernels read H * mask / (1 - rate) while H is what the slot records
-    limit = L.wn_range_limit() * ((1.0 - self.dropout) if (training and self.dropout > 0) else 1.0)
+    limit = _lib.lib().wn_range_limit() * ((1.0 - self.dropout) if (training and self.dropout > 0) else 1.0)
     return not (m < limit)
 
   def set_drop_step(self, n: int):
@@ -510,21 +521,23 @@ class WaveNet(torch.nn.Module):
     return loss, out, x[:, 1:, :]
 
   def train_step(self, data):
-    """src/model.py:309-348.  Data-parallel: the flat gradient (and the loss scalars) are
+    """src/model.py:309-348.  Data-parallel: the flat gradient (and the step's scalars) are
     SUM-all-reduced over RCCL before the (replicated, deterministic) optimizer step.
 
     Range guard: the split-precision kernels need |activation| < 65504.  The step's range flag rides in the bucket's
     tail through the all-reduce, the optimizer kernel skips the update on every replica when it is set, and the step is
-    then repeated here with the exact-fp32 kernels (same dropout mask, same optimizer iteration)."""
+    then repeated here with the exact-fp32 kernels (same dropout mask, same optimizer iteration); ``train_guard_trips``
+    counts those repeats (a tripped step costs a second, ~2.7x slower one)."""
     if self.optimizer is None:
       raise RuntimeError('compile(optimizer=...) first')
     lv, pending, y_true, sample = self._train_step_once(data)
     if lv[2] > 0:                                    # tripped on some replica -> on all of them after the SUM
+      self.train_guard_trips += 1
       self.optimizer.iterations -= 1
       self._drop_step -= 1 if self.dropout > 0 else 0
       with self.exact_fp32():
         lv, pending, y_true, sample = self._train_step_once(data)
-    for (m, _), v in zip(pending, lv[3:]):
+    for m, v in zip(pending, lv[3:]):
       m.commit(v)
     for metric in self.metrics:
       if metric.name == 'loss':
@@ -535,77 +548,92 @@ class WaveNet(torch.nn.Module):
         metric.update_state(y_true, sample)
     return {m.name: m.result() for m in self.metrics}
 
-  def _train_step_once(self, data):
-    want_metric = len(self._metrics_from_compilation) > 0
-    from . import dp
-    early = self.early_logs if self.early_logs is not None else self._world() == 1
-    if early:
-      # loss, reg_loss, the range flag and the sample metrics are final right after the loss kernels.  Their device-to-host
-      # copy is queued THERE, between the forward and the backward half of the step, and the host waits for that copy
-      # only -- it returns with 4 ms of the step still queued and has the next step's launches out before the GPU runs
-      # dry (reading the scalars at the end of the step costs a bubble of ~80 us per step).  Data-parallel: a copy of the
-      # scalars is SUM-all-reduced there (a few floats); the gradient bucket still carries its own {loss, reg_loss, flag}
-      # tail for the device-side skip of the optimizer.
-      st = {}
-      world = self._world()
+  def _mirror(self, vec):
+    """Queues the device-to-host copy of the step's scalars into pinned memory and records the event the host waits on."""
+    if self._log_mirror is None or self._log_mirror.numel() != vec.numel():
+      self._log_mirror = torch.empty(vec.numel(), dtype=torch.float32, pin_memory=True)
+      self._log_event = torch.cuda.Event()
+    self._log_mirror.copy_(vec, non_blocking=True)
+    self._log_event.record()
 
+  def _train_step_once(self, data):
+    """One pass of the step.  The scalars a step reports -- {loss, reg_loss, range flag, device-reduced metrics} -- live in
+    the gradient bucket's tail, each already scaled so that the SUM over the replicas is the reported value.
+
+    * single replica (no process group; ``early_logs`` True): they are final right after the loss kernels, so their
+      pinned copy is queued THERE, between the forward and the backward half, and the host waits for that copy only: it
+      returns with ~4 ms of the step still queued and has the next step's launches out before the GPU runs dry.
+    * data parallel (a process group exists; ``early_logs`` False): ONE collective per step -- the bucket's SUM
+      all-reduce carries gradients and tail together (train.py:203, src/model.py:328-336); the pinned copy of the reduced
+      tail is queued right behind it, the optimizer behind that, and the host waits for the copy's event (no blocking
+      ``tolist()`` at the end of the step).  ``early_logs = True`` under a process group instead all-reduces a copy of
+      the few scalars between forward and backward (a second, tiny collective) and reads them early."""
+    from . import dp
+    compiled = self._metrics_from_compilation
+    want_metric = len(compiled) > 0
+    dev_metrics = [m for m in compiled if hasattr(m, 'update_state_device')][:self._TAIL_METRICS]
+    early = self.early_logs if self.early_logs is not None else not dp.initialized()
+    world = self._world()
+    n = self.flat_params.numel()
+    tail = self._grad_bucket[n:]
+    nt = 3 + len(dev_metrics)
+
+    def queue_metrics(sample, y_true):
+      for i, m in enumerate(dev_metrics):
+        m.update_state_device(y_true, sample, out=tail[3 + i:4 + i], scale=1.0 / world)
+
+    if early:
       def between(loss, sample, y_true):
-        st['pending'] = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
-                         if hasattr(m, 'update_state_device')]
-        vec = torch.cat([loss] + [v for _, v in st['pending']])
-        if world > 1:
-          import torch.distributed as dist
-          dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-          vec[3:] /= world                             # metric values are means over a replica's rows (equal shares)
-        if self._log_mirror is None or self._log_mirror.numel() != vec.numel():
-          self._log_mirror = torch.empty(vec.numel(), dtype=torch.float32, pin_memory=True)
-          self._log_event = torch.cuda.Event()
-        self._log_mirror.copy_(vec, non_blocking=True)
-        self._log_event.record()
+        queue_metrics(sample, y_true)
+        vec = tail[:nt]
+        if dp.initialized():
+          vec = vec.clone()
+          dp.allreduce_bucket(vec)
+        self._mirror(vec)
       loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True, _between=between)
-      dp.allreduce_bucket(self._grad_bucket)            # gradients + {loss, reg_loss, range_flag}; no-op for a single replica
-      self.optimizer.apply_gradients(self, skip_flag=loss[2:3])
-      self._log_event.synchronize()
-      return self._log_mirror.tolist(), st['pending'], y_true, sample
-    loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True)
-    dp.allreduce_bucket(self._grad_bucket)              # gradients + {loss, reg_loss, range_flag}; no-op for a single replica
-    self.optimizer.apply_gradients(self, skip_flag=loss[2:3])
-    # metrics that can reduce on the device do so behind the optimizer; ONE read brings back loss, reg_loss, flag and them
-    pending = [(m, m.update_state_device(y_true, sample)) for m in self._metrics_from_compilation
-               if hasattr(m, 'update_state_device')]
-    mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
-    lv = (torch.cat([loss, mv]) if pending else loss).tolist()
-    return lv, pending, y_true, sample
+      dp.allreduce_bucket(self._grad_bucket)            # gradients + tail; no-op without a process group
+      self.optimizer.apply_gradients(self, skip_flag=tail[2:3])
+    else:
+      loss, sample, y_true = self.loss_and_grads(data, want_sample=want_metric, _loss_in_bucket=True)
+      queue_metrics(sample, y_true)
+      dp.allreduce_bucket(self._grad_bucket)            # the step's ONE collective: gradients + {loss, reg_loss, flag, metrics}
+      self._mirror(tail[:nt])
+      self.optimizer.apply_gradients(self, skip_flag=tail[2:3])
+    self._log_event.synchronize()
+    return self._log_mirror.tolist(), dev_metrics, y_true, sample
 
   def test_step(self, data):
-    """src/model.py:362-391 (range guard as in train_step: a tripped pass is repeated with the exact-fp32 kernels)."""
+    """src/model.py:362-391 (range guard as in train_step: a tripped pass is repeated with the exact-fp32 kernels and
+    counted in ``test_guard_trips``)."""
+    from . import dp
     x, cond = self._split_inputs(data)
     B, T = x.shape[0], x.shape[1] - 1
     world = self._world()
     L = _lib.lib()
     ws = self._workspace('fwd', L.wn_plan_workspace_floats(self._plan, B, T, 0))
-    loss = torch.empty(3, dtype=torch.float32, device=self._device)
-    want_metric = len(self._metrics_from_compilation) > 0
+    compiled = self._metrics_from_compilation
+    want_metric = len(compiled) > 0
+    dev_metrics = [m for m in compiled if hasattr(m, 'update_state_device')][:self._TAIL_METRICS]
+    vec = torch.zeros(3 + len(dev_metrics), dtype=torch.float32, device=self._device)
     pred = torch.empty(B, T, self.spec.out_channels, dtype=torch.float32, device=self._device) if want_metric else None
 
     def once():
       _lib.check(L.wn_eval_loss(self._plan, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(cond), B, T,
-                                B * world, _lib.ptr(loss), _lib.ptr(pred), _lib.ptr(ws), ws.numel(),
+                                B * world, _lib.ptr(vec), _lib.ptr(pred), _lib.ptr(ws), ws.numel(),
                                 _lib.stream_ptr()))
-      if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(loss, op=dist.ReduceOp.SUM)      # loss sums over the replicas; reg_loss unused; flag: any replica
       sample = self.sample_waveform(pred) if want_metric else None
-      # as in train_step: device-side metric reductions first, then ONE device-to-host read
-      pending = [(m, m.update_state_device(x[:, 1:, :], sample)) for m in self._metrics_from_compilation
-                 if hasattr(m, 'update_state_device')]
-      mv = self._replica_mean(torch.cat([v for _, v in pending])) if pending else None
-      return (torch.cat([loss, mv]) if pending else loss).tolist(), pending, sample
-    lv, pending, sample = once()
+      # as in train_step: device-side metric reductions into the same vector, ONE collective (loss sums over the replicas;
+      # reg_loss unused; flag: any replica; metrics: replica means), ONE device-to-host read
+      for i, m in enumerate(dev_metrics):
+        m.update_state_device(x[:, 1:, :], sample, out=vec[3 + i:4 + i], scale=1.0 / world)
+      dp.allreduce_bucket(vec)
+      return vec.tolist(), sample
+    lv, sample = once()
     if lv[2] > 0:
+      self.test_guard_trips += 1
       with self.exact_fp32():
-        lv, pending, sample = once()
-    for (m, _), v in zip(pending, lv[3:]):
+        lv, sample = once()
+    for m, v in zip(dev_metrics, lv[3:]):
       m.commit(v)
     for metric in self.metrics:
       if metric.name == 'loss':
@@ -699,7 +727,7 @@ class WaveNet(torch.nn.Module):
     if length > 0 and L.wn_debug_value(1) != 1:
       slot = L.wn_generate_guard_slot(self._plan, batch_size, int(bool(use_queues)))
       if not (float(ws[slot]) < L.wn_range_limit()):
-        self.generation_guard_trips = getattr(self, 'generation_guard_trips', 0) + 1
+        self.generation_guard_trips += 1
         with self.exact_fp32():
           run()
     return out
