@@ -569,6 +569,8 @@ class WaveNet(torch.nn.Module):
       ``tolist()`` at the end of the step).  ``early_logs = True`` under a process group instead all-reduces a copy of
       the few scalars between forward and backward (a second, tiny collective) and reads them early."""
     from . import dp
+    if not self.built:
+      self._split_inputs(data)                          # Keras builds on the first call (the condition width fixes the shapes)
     compiled = self._metrics_from_compilation
     want_metric = len(compiled) > 0
     dev_metrics = [m for m in compiled if hasattr(m, 'update_state_device')][:self._TAIL_METRICS]
