@@ -21,15 +21,3 @@ def pytest_collection_modifyitems(config, items):
   for item in items:
     if 'gpu' in item.keywords:
       item.add_marker(skip)
-
-
-@pytest.fixture(scope='session', autouse=True)
-def _debug_knobs_from_env():
-  """WN_KNOBS="4=1,16=3": run the suite under non-default kernel variants (tools/ A/B runs check parity this way)."""
-  spec = os.environ.get('WN_KNOBS', '')
-  if spec:
-    from wavenets_amd import _lib
-    for item in spec.split(','):
-      k, v = item.split('=')
-      _lib.lib().wn_debug_set(int(k), int(v))
-  yield

@@ -947,126 +947,34 @@ def test_train_step_in_two_calls_equals_one_call(name):
       assert abs(la[k_] - lb[k_]) <= 1e-6 * max(1.0, abs(la[k_])), (k_, la[k_], lb[k_])
 
 
-def test_categorical_loss_kernel_forms_agree_bitwise():
-  """The persistent, next-row-prefetching loss kernel for <= 256 classes and the one-row-per-wave kernel (knob 28) run the
-  same arithmetic per row: loss, every gradient and the in-kernel sample_waveform draw are bit-identical (ragged row
-  count: more rows than one pass of the persistent grid, not a multiple of 4)."""
-  from wavenets_amd import _lib
-  kw = dict(MODEL_CASES['cat_small_fused'])
-  ocfg, params, model = make_pair(seed=3, bias_range=0.3, **kw)
-  x = O.synthetic_waveform(3, 2731 + 1, seed=21).to(dev())          # 8193 rows
-  L = _lib.lib()
-  res = []
-  for knob in (0, 1):
-    try:
-      L.wn_debug_set(28, knob)
-      model._sample_calls = 7                          # the draw's Philox offset: the same for both forms
-      loss, samp, _ = model.loss_and_grads(x, want_sample=True)
-      res.append((loss.clone(), None if samp is None else samp.clone(), model.flat_grads.clone()))
-    finally:
-      L.wn_debug_set(28, 0)
-  assert torch.equal(res[0][0][:2], res[1][0][:2])
-  assert torch.equal(res[0][2], res[1][2])
-  assert res[0][1] is not None and torch.equal(res[0][1], res[1][1])
-
-
-def test_forward_guard_check_can_be_deferred():
-  """range_check = False skips the per-call host read of the forward range guard; the deferred check reads the same slot."""
-  kw = dict(MODEL_CASES['cat_r64'])
-  ocfg, params, model = make_pair(seed=2, **kw)
-  x, _ = _inputs(kw, 2, 257)
-  ref = model(x.to(dev()))
-  model.range_check = False
-  out = model(x.to(dev()))
-  assert torch.equal(ref, out) and model.range_tripped_last_forward() is False
-  with torch.no_grad():
-    model.flat_params.mul_(3.0e3)                      # drive the residual stream beyond the fp16 range
-  model(x.to(dev()))
-  assert model.range_tripped_last_forward() is True
-
-
-@pytest.mark.parametrize('name', ['cat_r64', 'cat_r32_f128'])
-def test_fold_weight_space_products_and_reductions_agree_bitwise(name):
-  """The folded skip path's small weight-space products on the 32 x 32-tile kernel (one round trip per 128 k) and on the
-  64 x 64-tile kernel (knob 32) run the same fma chain per element: loss and every parameter gradient are bit-identical."""
-  from wavenets_amd import _lib
-  kw = dict(MODEL_CASES[name])
-  ocfg, params, model = make_pair(seed=5, bias_range=0.3, **kw)
-  x = O.synthetic_waveform(3, 700 + 1, seed=23).to(dev())
-  L = _lib.lib()
-  res = []
-  for knob in (0, 1):
-    try:
-      L.wn_debug_set(32, knob)
-      loss, _, _ = model.loss_and_grads(x)
-      res.append((loss.clone(), model.flat_grads.clone()))
-    finally:
-      L.wn_debug_set(32, 0)
-  assert torch.equal(res[0][0][:2], res[1][0][:2])
-  assert torch.equal(res[0][1], res[1][1])
-
-
 @pytest.mark.parametrize('name,det', [('cat_r64', True), ('cat_r64', False), ('cat_small_fused', False), ('mol', False)])
-def test_queued_generation_launch_variants_agree(name, det):
-  """The queued sampler's launch variants draw the same samples as the sliding window: the first chain kernel (knob 23),
-  no L2 helper workgroups (25), the pre kernel as its own launch (26), the sampling tail as its own launch (27), softmax /
-  sampler / emit as separate kernels (6 = 3), skip contraction as its own launch (6 = 2)."""
-  from wavenets_amd import _lib
+def test_queued_generation_draws_the_sliding_windows_samples(name, det):
+  """The queued sampler (chain launch + head launch with the sampling tail, or sampler + emit in one launch for mixture
+  heads) draws the samples of the sliding window, stochastic draws included (same Philox counters), at 5 utterances."""
   kw = dict(MODEL_CASES[name])
   ocfg, params, model = make_pair(seed=11, bias_range=0.3, **kw)
   B, n = 5, 14
   w = O.synthetic_waveform(B, model.receptive_field, seed=12).to(dev())
   naive = model.generate(n, sample=w, use_queues=False, deterministic=det)
-  L = _lib.lib()
-  for key, val in ((0, 0), (23, 1), (25, 1), (26, 1), (27, 1), (27, 2), (6, 3), (6, 2)):
-    try:
-      L.wn_debug_set(key, val)
-      queued = model.generate(n, sample=w, use_queues=True, deterministic=det)
-    finally:
-      L.wn_debug_set(key, 0)
-    assert torch.equal(naive, queued), (key, val, (naive - queued).abs().max())
+  queued = model.generate(n, sample=w, use_queues=True, deterministic=det)
+  assert torch.equal(naive, queued), (naive - queued).abs().max()
 
 
-@pytest.mark.parametrize('name', ['cat_r64', 'cat_r32_f128'])
-@pytest.mark.parametrize('T', [333, 64, 2048 + 17])
-def test_folded_contraction_streamed_forms_agree_bitwise(name, T):
-  """The folded skip contraction's second streamed kernel (wn_gemm16s.hip: four-wave workgroups, two row tiles per wave,
-  weight stream across tiles) runs the old kernel's products in the old order: outputs and logits are bit-identical with
-  knob 31 (old kernel) and knob 30 (one row tile per wave), for ragged tiles too."""
-  from wavenets_amd import _lib
-  kw = dict(MODEL_CASES[name])
-  ocfg, params, model = make_pair(seed=21, bias_range=0.3, **kw)
-  x, _ = _inputs(kw, 3, T, seed=5)
-  L = _lib.lib()
-  ref = model.logits(x.to(dev()))
-  for key in (31, 30):
-    try:
-      L.wn_debug_set(key, 1)
-      other = model.logits(x.to(dev()))
-    finally:
-      L.wn_debug_set(key, 0)
-    assert torch.equal(ref, other), (key, (ref - other).abs().max())
-
-
-@pytest.mark.parametrize('skip_channels,finals', [(160, [64]), (256, [128, 256]), (96, [32]), (192, [64, 64])])
+@pytest.mark.parametrize('skip_channels,finals', [(160, [48]), (256, [256, 64]), (96, [32]), (192, [])])
 def test_queued_generation_unfolded_skip_contraction(skip_channels, finals):
-  """With the fold switched off (knob 21) the chain kernel carries the reference's full-width skip contraction: 3, 5, 6 and
-  8 column tiles, i.e. two to four skip waves of two tiles each on the two-phase schedule (the folded default needs at
+  """Heads the fold does not apply to (first head conv narrower than 64 or not a multiple of 32 columns, as wide as the
+  skip sum, or no hidden head layer at all): the chain kernel carries the reference's full-width skip contraction -- 5, 8,
+  3 and 6 column tiles, i.e. two to four skip waves of two tiles each on the two-phase schedule (the folded default needs at
   most four tiles and runs both in phase C)."""
-  from wavenets_amd import _lib
   kw = dict(blocks=5, channels=64 if skip_channels == 256 else 32, skip_channels=skip_channels, dilation_bound=8,
             final_layers_channels=finals, activation='leaky_relu', bits=8)
   ocfg, params, model = make_pair(seed=13, bias_range=0.3, **kw)
+  assert 'folded' not in model.kernel_report()
   w = O.synthetic_waveform(5, model.receptive_field, seed=14).to(dev())
-  L = _lib.lib()
-  try:
-    L.wn_debug_set(21, 1)
-    naive = model.generate(12, sample=w, use_queues=False, deterministic=True)
-    queued = model.generate(12, sample=w, use_queues=True, deterministic=True)
-    queued_s = model.generate(12, sample=w, use_queues=True, deterministic=False)
-    naive_s = model.generate(12, sample=w, use_queues=False, deterministic=False)
-  finally:
-    L.wn_debug_set(21, 0)
+  naive = model.generate(12, sample=w, use_queues=False, deterministic=True)
+  queued = model.generate(12, sample=w, use_queues=True, deterministic=True)
+  queued_s = model.generate(12, sample=w, use_queues=True, deterministic=False)
+  naive_s = model.generate(12, sample=w, use_queues=False, deterministic=False)
   assert torch.equal(naive, queued)
   assert torch.equal(naive_s, queued_s)
 
@@ -1085,10 +993,8 @@ def test_queued_generation_ring_wraparound():
 @pytest.mark.parametrize('B,cond', [(3, False), (40, False), (5, True)])
 def test_queued_generation_128_channel_chain(B, cond):
   """128-channel blocks: every block of a step, the input conv and the folded skip contraction in one launch
-  (wn_gen_chain128_kernel) -- one and two utterance tiles, rings that wrap, with and without global conditioning -- and
-  the per-block launch forms (knob 34 = 2: wn_gen_block128_kernel, = 1: the streamed forward kernel) draw the sliding
-  window's samples."""
-  from wavenets_amd import _lib
+  (wn_gen_chain128_kernel) -- one and two utterance tiles, rings that wrap, with and without global conditioning -- draws
+  the sliding window's samples."""
   kw = dict(blocks=5, channels=128, skip_channels=256, dilation_bound=16, final_layers_channels=[128, 64],
             activation='leaky_relu', bits=8)
   if cond:
@@ -1100,14 +1006,8 @@ def test_queued_generation_128_channel_chain(B, cond):
   if cond:
     args['condition'] = c
   naive = model.generate(40, use_queues=False, **args)
-  L = _lib.lib()
-  for knob in (0, 2, 1):
-    try:
-      L.wn_debug_set(34, knob)
-      queued = model.generate(40, use_queues=True, **args)
-    finally:
-      L.wn_debug_set(34, 0)
-    assert torch.equal(naive, queued), (knob, (naive - queued).abs().max())
+  queued = model.generate(40, use_queues=True, **args)
+  assert torch.equal(naive, queued), (naive - queued).abs().max()
 
 
 def test_plan_caches_survive_shape_changes():
@@ -1147,41 +1047,34 @@ def test_wide_blocks_gradients_ragged(B, T, math_mode):
 
 
 def test_wide_blocks_forward_paths_agree():
-  """The composed split-precision forward of 128-channel blocks against the exact-fp32 one-kernel forward
-  (debug knob 11) on the same weights: activations within the 1e-4 bar at a length with many tiles."""
-  from wavenets_amd import _lib
+  """The streamed split-precision forward of 128-channel blocks against the exact-fp32 kernels on the same weights:
+  activations within the 1e-4 bar at a length with many tiles."""
   kw = dict(MODEL_CASES['cat_r128'])
   ocfg, params, model = make_pair(seed=21, **kw)
   x = O.synthetic_waveform(2, 4100, seed=22).to(dev())
-  try:
-    _lib.lib().wn_debug_set(11, 1)
+  with model.exact_fp32():
     ref = model.logits(x).clone()
-  finally:
-    _lib.lib().wn_debug_set(11, 0)
   out = model.logits(x)
   assert not torch.equal(out, ref)                        # two different kernels really ran
   assert (out - ref).abs().max().item() < ATOL_ACT
 
 
-def test_wide_skip_contraction_is_bit_identical_to_column_blocks():
-  """The folded skip sum (K = blocks * D >= 512, N = 256) runs on the 256-column streamed kernel; debug knob 12
-  sends it through the 128-column kernel instead.  Same per-element MFMA sequence -> identical bits; and both
-  match the oracle.  The wide kernel takes over from 2048 row tiles on (enough to fill the chip with one column
-  block); T is off the 32-step tile and the tile count does not fill the last workgroup."""
-  from wavenets_amd import _lib
-  kw = dict(blocks=9, channels=64, skip_channels=256, dilation_bound=16, final_layers_channels=[128, 256],
+def test_wide_skip_contraction_matches_oracle():
+  """The unfolded skip sum (K = blocks * D >= 512, N = 256: exact-fp32 mode aside, a head whose first conv is as wide as
+  the skip sum) runs on the 256-column streamed kernel from 2048 row tiles on (enough to fill the chip with one column
+  block) and on the 128-column kernel below that: both against the oracle.  T is off the 32-step tile and the tile count
+  does not fill the last workgroup."""
+  kw = dict(blocks=9, channels=64, skip_channels=256, dilation_bound=16, final_layers_channels=[256, 64],
             activation='leaky_relu', bits=8)
   ocfg, params, model = make_pair(seed=31, **kw)
+  assert 'folded' not in model.kernel_report()
   x = O.synthetic_waveform(9, 7301, seed=32)          # 9 x 229 = 2061 row tiles, the last of each utterance holds 5 rows
   out = model.logits(x.to(dev())).clone()
-  try:
-    _lib.lib().wn_debug_set(12, 1)
-    ref = model.logits(x.to(dev())).clone()
-  finally:
-    _lib.lib().wn_debug_set(12, 0)
-  assert torch.equal(out, ref)
+  small = model.logits(x[:2].to(dev())).clone()        # 458 row tiles: the 128-column kernel
   _, inter = O.model_forward(x[:2].double(), [p.double() for p in params], ocfg, None, return_intermediates=True)
   assert (out[:2].cpu().double() - inter['logits']).abs().max() < ATOL_ACT      # (oracle on two of the utterances)
+  assert (small.cpu().double() - inter['logits']).abs().max() < ATOL_ACT
+  assert torch.equal(out[:2], small)                   # same per-element MFMA sequence in both kernels
 
 
 @pytest.mark.parametrize('name', ['cat_r64', 'mol', 'gauss'])
@@ -1233,26 +1126,13 @@ def test_train_step_metric_sample_wide_categorical_heads(bits):
 
 
 def test_head_weight_gradients_on_their_own_time_split():
-  """At longer utterances the head's weight gradients are accumulated over a finer time split than the
-  blocks' (own compact slab, debug knob 0 = -1 shares the blocks').  Both arrangements against the oracle, and
-  against each other, on every gradient tensor."""
-  from wavenets_amd import _lib
+  """At longer utterances the head's weight gradients are accumulated over a finer time split than the blocks' (own
+  compact slab): every gradient tensor against the oracle."""
   kw = dict(MODEL_CASES['cat_r64'], blocks=10, dilation_bound=32)
   ocfg, params, model = make_pair(seed=61, **kw)
   x = O.synthetic_waveform(8, 3001, seed=62)      # 8 x 3000, 68 jobs: the blocks split each utterance 10-fold, the head 12-fold
   _, _, grads_ref, _ = O.loss_and_grads(x.double(), [p.double() for p in params], ocfg)
-  got = {}
-  for knob in (0, -1):
-    try:
-      _lib.lib().wn_debug_set(0, knob)
-      model.loss_and_grads(x.to(dev()))
-      got[knob] = [g.clone() for g in model.gradients()]
-    finally:
-      _lib.lib().wn_debug_set(0, 0)
-  differ = 0
-  for n, a, b, r in zip(model.variable_names, got[0], got[-1], grads_ref):
+  model.loss_and_grads(x.to(dev()))
+  for n, a, r in zip(model.variable_names, model.gradients(), grads_ref):
     scale = max(r.abs().max().item(), 1e-6)
     assert (a.cpu().double() - r).abs().max().item() < 1e-4 * scale + 1e-7, n
-    assert (b.cpu().double() - r).abs().max().item() < 1e-4 * scale + 1e-7, n
-    differ += int(not torch.equal(a, b))
-  assert differ > 0          # a different summation order really ran (head tensors only)

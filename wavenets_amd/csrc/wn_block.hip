@@ -48,8 +48,8 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
   if (f.pre_done && k.depth > 1) { h = nullptr; hc = k.D; }
   for (int i = 0; i + 1 < k.depth && !f.pre_done; ++i) {
     const bool i16 = k.F16i[i] != nullptr;            // (training passes of deep stacks: split-precision, see deep16_ptrs)
-    // 32 / 64 channels: the streamed kernel's second form with the taps as shifted planes (knob 36 = 1: the rows GEMM)
-    if (i16 && k.JTi[i] == 2 && k.KS <= 4 && wn_debug_get(36) != 1 && wn_gemm_taps16s_supported(k.D, hc, k.KS, hc, k.D) &&
+    // 32 / 64 channels: the streamed kernel's second form with the taps as shifted planes (the rows GEMM for other widths)
+    if (i16 && k.JTi[i] == 2 && k.KS <= 4 && wn_gemm_taps16s_supported(k.D, hc, k.KS, hc, k.D) &&
         (int64_t)rows * hc * 4 < ((int64_t)1 << 32)) {
       WnGemmPlanesArgs ga;
       memset(&ga, 0, sizeof(ga));
@@ -72,9 +72,9 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
   }
   const int li = k.depth - 1;
   // blocks too wide for LDS-resident weights (R = D = 128): one kernel that streams the fp16 hi|lo images through an LDS
-  // ring and keeps u and z on chip (wn_layer16s.hip); knob 11 = 2 -> the two-contraction form below, = 1 -> exact fp32
+  // ring and keeps u and z on chip (wn_layer16s.hip)
   if (k.F16n && k.F16r && k.depth == 1 && k.Cc == 0 && hc == k.R && k.Cin == k.R && f.ldz % 4 == 0 && wn_debug_get(1) != 1 &&
-      wn_debug_get(11) == 0 && wn_layer_fwd_s128_supported(k.R, k.D, k.KS) && (int64_t)rows * k.R * 4 < ((int64_t)1 << 32)) {
+      wn_layer_fwd_s128_supported(k.R, k.D, k.KS) && (int64_t)rows * k.R * 4 < ((int64_t)1 << 32)) {
     WnLayerFwdArgs a;
     memset(&a, 0, sizeof(a));
     a.x = h; a.frag_d = k.F16n; a.frag_r = k.F16r;
@@ -85,15 +85,14 @@ int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s) {
     a.B = k.B; a.T = k.T; a.R = k.R; a.D = k.D; a.KS = k.KS; a.dilation = k.dil[li]; a.residual = k.residual;
     a.absmax_out = f.fwd_absmax;
     // one row per utterance (a queued-generation step): the whole block in one workgroup with every weight fragment
-    // requested up front instead of the streamed pipeline (wn_gen128.hip, same arithmetic; knob 34 = 1: the streamed kernel)
-    if (k.T == 1 && f.xt[0] && f.xt[1] && !f.AG && wn_debug_get(34) != 1 && wn_gen_block128_supported(k.R, k.D, k.KS))   // (34 = 2 too)
+    // requested up front instead of the streamed pipeline (wn_gen128.hip, same arithmetic)
+    if (k.T == 1 && f.xt[0] && f.xt[1] && !f.AG && wn_gen_block128_supported(k.R, k.D, k.KS))
       return wn_launch_gen_block128(a, s);
     return wn_launch_layer_fwd_s128(a, s);
   }
-  // the same blocks as [gated conv + gate] -> [1x1 + residual], two split-precision contractions, ahead of the exact-fp32
-  // one-kernel forward   (knob 11 = 1 disables it)
-  if (k.F16g && k.F16r && k.Cc == 0 && !k.cb && !f.O && hc == k.R && f.ldz % 4 == 0 && wn_debug_get(1) != 1 &&
-      wn_debug_get(11) != 1) {
+  // wider blocks (or other kernel sizes) as [gated conv + gate] -> [1x1 + residual], two split-precision contractions, ahead of
+  // the exact-fp32 one-kernel forward
+  if (k.F16g && k.F16r && k.Cc == 0 && !k.cb && !f.O && hc == k.R && f.ldz % 4 == 0 && wn_debug_get(1) != 1) {
     Gemm g(k.B, k.T, 2 * k.D, ceil32(2 * k.D));
     for (int t = 0; t < k.KS; ++t) {
       if (f.xt[t]) g.seg(f.xt[t], hc, hc, 0, nullptr);
@@ -174,13 +173,11 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     const bool pad_u = k.JTu > 0 && k.G16u && full_u && k.Cc == 0 && g.am_gu &&
                        ((g_o == g.g_xout) ? g.am_gxout : (g_o == g.g_skip ? g.am_gskip : g.am_gxout)) != nullptr;
     Gemm gm(k.B, k.T, k.D, pad_u ? k.JTu : ceil32(k.D));
-    const bool use_gzs = g.gzs && g_o && k.G16r && g.am_gu && g.am_gxout && k.Cc == 0;
     const bool use_fold = g.g_fold && g_o && k.G16uf && g.am_gu && g.am_gxout && g.am_gfold && k.Cc == 0;
     if (g_o) gm.seg(g_o, k.R, k.R, 0, (use_fold || pad_u) ? nullptr : k.Br_);
     if (use_fold) gm.seg(g.g_fold, g.fold_F0, g.fold_F0, 0, nullptr).w16(k.G16uf).absmax(g.am_gxout, g.am_gfold, g.am_gu);
-    else if (use_gzs) gm.addc(g.gzs, g.ld_gzs).w16(k.G16r).absmax(g.am_gxout, nullptr, g.am_gu);
     else if (k.S > 0 && g.g_skip) gm.seg(g.g_skip, k.S, k.S, 0, pad_u ? nullptr : k.Bs);
-    if (use_gzs || use_fold) {
+    if (use_fold) {
       rc = gm.gate_bwd(f.AG, k.D, f.Z, f.ldz).run(g.g_u, 2 * k.D, s);
     } else if (gm.a.nseg == 0) {
       rc = wn_launch_fill(g.g_u, 0.f, rows * 2 * k.D, s);
@@ -249,8 +246,8 @@ int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, 
     float* am_dst = (i > 0) ? g.am_gp[i - 1] : g.am_gx;
     const bool b16 = k.depth > 1 && k.G16i[i] && am_cur && am_dst;
     // inner convs (their output gradient gets act' folded in): the streamed kernel's second form, backward-data
-    // instantiation with the taps as negatively shifted planes (knob 36 = 1: the rows GEMM)
-    if (b16 && i > 0 && k.JTb[i] == 2 && k.KS <= 4 && wn_debug_get(36) != 1 && wn_gemm_taps16s_supported(hc, gc, k.KS, gc, hc) &&
+    // instantiation with the taps as negatively shifted planes (the rows GEMM for other widths)
+    if (b16 && i > 0 && k.JTb[i] == 2 && k.KS <= 4 && wn_gemm_taps16s_supported(hc, gc, k.KS, gc, hc) &&
         (int64_t)rows * gc * 4 < ((int64_t)1 << 32)) {
       float* dst = g.g_pi[i - 1] ? g.g_pi[i - 1] : g.g_p + (int64_t)((i & 1) ? 0 : rows * k.D);
       WnGemmPlanesArgs ga;

@@ -162,4 +162,4 @@ __device__ __forceinline__ void wn_guard_publish_over(float* slot, float wmax) {
 }
 
 void wn_set_error(const char* fmt, ...);
-int wn_debug_get(int key);   // tuning knobs (wn_error.cpp): 0 = layer-forward kernel variant
+int wn_debug_get(int key);   // per-thread switches (wn_error.cpp): 1 = exact-fp32 kernels, 9 = no side stream, 24 / 29 = profiling hooks

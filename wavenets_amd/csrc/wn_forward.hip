@@ -51,7 +51,6 @@ BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* 
   if (bi.f16gate >= 0) { k.F16g = fragbase + bi.f16gate; k.F16r = fragbase + bi.conv1.frag16; }
   if (bi.f16nat >= 0) k.F16n = fragbase + bi.f16nat;
   if (bi.g16u >= 0 && p->LPB == 1) k.G16u = fragbase + bi.g16u;
-  if (bi.g16r >= 0) k.G16r = fragbase + bi.g16r;
   if (bi.g16uf >= 0) k.G16uf = fragbase + bi.g16uf;
   if (p->LPB == 1 && bi.dil[0].frag16B >= 0) k.G16x = fragbase + bi.dil[0].frag16B;
   return k;
@@ -238,9 +237,9 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   if (fold) {
     // a = act(sum_b V(b)^T z_b + b'): the skip sum and the head's first conv in ONE contraction with F0 output columns
     const ConvInfo& c0 = p->finals[0];
-    // streamed kernel, second form (wn_gemm16s.hip: bit-identical results; knob 31 = 1: wn_gemm_rows16_kernel)
+    // streamed kernel, second form (wn_gemm16s.hip; other shapes: wn_gemm_rows16_kernel, the same products in the same order)
     // (the streamed form indexes rows with 32-bit byte offsets: beyond 4 GiB per plane the rows GEMM takes over)
-    if (wn_debug_get(31) != 1 && p->Dp == p->D && wn_gemm_planes16s_supported(c0.cout, p->D, p->N, p->Dp, c0.cout) &&
+    if (p->Dp == p->D && wn_gemm_planes16s_supported(c0.cout, p->D, p->N, p->Dp, c0.cout) &&
         (int64_t)rows * p->Dp * 4 < ((int64_t)1 << 32) && (int64_t)rows * c0.cout * 4 < ((int64_t)1 << 32)) {
       WnGemmPlanesArgs ga;
       memset(&ga, 0, sizeof(ga));
@@ -272,8 +271,8 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     const bool last = (i + 1 == p->finals.size());
     float* dst = last ? ws + L.logits : ws + L.HA[i];
     // 128 / 256 output columns: the streamed kernel's second form (wn_gemm16s.hip; the operand is one "plane"); same
-    // products in the same order as the rows GEMM below (knob 31 = 1)
-    if (c.frag16 >= 0 && wn_debug_get(1) != 1 && wn_debug_get(31) != 1 && wn_gemm_planes16s_supported(c.cout, hc, 1, hc, c.cout) &&
+    // products in the same order as the rows GEMM below
+    if (c.frag16 >= 0 && wn_debug_get(1) != 1 && wn_gemm_planes16s_supported(c.cout, hc, 1, hc, c.cout) &&
         (int64_t)rows * hc * 4 < ((int64_t)1 << 32)) {
       WnGemmPlanesArgs ga;
       memset(&ga, 0, sizeof(ga));
@@ -309,7 +308,7 @@ int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float
   const float gscale = 1.0f / (float)global_batch;     // compute_average_loss, src/model.py:328-329
   int rc;
   // deferred weight gradients read d loss / d logits from GF.back(): written there directly (no 131 MB copy)
-  float* g_logits = want_grad ? ((deferred_wgrad(p) && !L.GF.empty()) ? ws + L.GF.back() : ws + L.g_a) : nullptr;
+  float* g_logits = want_grad ? ws + L.GF.back() : nullptr;
   if (p->c.head == WN_HEAD_CATEGORICAL) {
     rc = wn_launch_quantize(ws + L.yt, reinterpret_cast<int32_t*>(ws + L.target), rows, p->c.bits, s);
     if (rc) return rc;

@@ -865,14 +865,13 @@ int wn_launch_gemm_rows16(const WnGemmArgs& a, const float* w16, const float* ab
     return WN_OK;
   }
   // long contractions with 256 output channels over enough rows to fill the chip with one column block (fewer rows,
-  // e.g. the sliding-window sampler's: two column blocks give twice the workgroups); knob 12 = 1: never
-  if (jt_need == 8 && a.JTtot == 8 && a.epi == WN_EPI_PLAIN && nks >= 32 && tiles >= 2048 && wn_debug_get(12) != 1) {
+  // e.g. the sliding-window sampler's: two column blocks give twice the workgroups)
+  if (jt_need == 8 && a.JTtot == 8 && a.epi == WN_EPI_PLAIN && nks >= 32 && tiles >= 2048) {
     hipLaunchKernelGGL((wn_gemm_rows16_wide_kernel<WN_EPI_PLAIN>), dim3((unsigned)gx), dim3(512), 0, s, a, w16, nks, absmax_in0, absmax_in1, absmax_out);
     WN_HIP_CHECK(hipGetLastError());
     return WN_OK;
   }
-  // knob 2 = 1 disables the resident form
-  if (jt_need <= 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES && wn_debug_get(2) != 1 &&
+  if (jt_need <= 2 && a.JTtot == 2 && (int64_t)nks * 2 * 2048 <= WnG16R<2>::MAX_W_BYTES &&
       nks % WnG16R<2>::PF == 0 &&
       a.seg[0].plane_k == 0) {
     // (the forms that fetch their epilogue operands ahead read all 64 columns of them: not for a padded 32-column product)

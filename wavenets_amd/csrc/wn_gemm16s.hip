@@ -264,8 +264,8 @@ int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
   }
   if ((int64_t)a.B * a.T * a.ld * 4 >= (int64_t)1 << 32) { wn_set_error("gemm_planes16s: plane beyond 4 GiB"); return WN_E_UNSUPPORTED; }
   if ((int64_t)a.B * a.T <= 0) return WN_OK;
-  // 128 columns: two row tiles per wave (knob 30 = 1: one, A/B); 256 columns: one (128 accumulator registers either way)
-  const int rt = a.N <= 64 ? 2 : ((a.N == 256 || wn_debug_get(30) == 1) ? 1 : 2);
+  // 128 columns: two row tiles per wave; 256 columns: one (128 accumulator registers either way)
+  const int rt = a.N == 256 ? 1 : 2;
   const int64_t tiles = (int64_t)a.B * ((a.T + 32 * rt - 1) / (32 * rt));
   int64_t gx = (tiles + 3) / 4;
   if (gx > 512) gx = 512;                                // two persistent workgroups of four waves per CU
@@ -290,7 +290,6 @@ int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
     case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH(1, 8, WN_ACT_LEAKY_RELU); break;
     default: WN_GS_LAUNCH(1, 8, -1); break;
   }
-  else if (rt == 1) WN_GS_LAUNCH(1, 4, -1);
   else switch (a.act) {
     case WN_ACT_LINEAR: WN_GS_LAUNCH(2, 4, WN_ACT_LINEAR); break;
     case WN_ACT_RELU: WN_GS_LAUNCH(2, 4, WN_ACT_RELU); break;

@@ -124,293 +124,6 @@ __global__ __launch_bounds__(64) void wn_gen_pre_kernel(WnGenStepArgs a) {
 // the global prefetches and LDS-DMA that are meant to stay in flight across phases
 #define GN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// Chain kernel: one workgroup per 32 utterances, JU = 2 * D / 32 "chain" waves + up to 8 "skip" waves.
-//   phase A  chain wave w: u tile w = u0 + W_{k-1}^T x        (x as ready-made hi|lo B operands in LDS)
-//   phase B  chain wave w: gated activation of z k-step w  -> z row (HBM) and z hi|lo B operand (LDS)
-//   phase C  chain wave j < R / 32: o tile j = b_r + W_r^T z, x_next = o (+ x) -> next ring slot, x operands
-//            skip wave s: acc_s += W_{s,b}^T z   (the folded skip contraction, k order = block order)
-// Every wave brings the weight fragments of ITS tile for block b + 1 into its own corner of the other
-// LDS half by LDS-DMA while block b runs, so weights need neither registers nor cross-wave ordering.
-template <int R32, int D32, int KS>
-__global__ __launch_bounds__(64 * (2 * D32 + 8)) void wn_gen_chain_kernel(WnGenStepArgs a) {
-  using S = GnShape<R32, D32, KS>;
-  constexpr int R = S::R, D = S::D, JU = S::JU, KSR = S::KSR, KS0 = S::KS0, KS2 = S::KS2;
-  // one LDS half per block parity: [newest-tap fragments | conv1 fragments | u0 image (reused as the u
-  // exchange buffer once consumed) | conv1 bias, one 256 B copy per conv1 wave]
-  constexpr int U0_OFF = S::WD_BYTES + S::WR_BYTES, BR_OFF = U0_OFF + S::U0_BYTES;
-  constexpr int HALF = BR_OFF + R32 * 256;
-  constexpr int XOP_BYTES = KSR * 2048, ZOP_BYTES = KS2 * 2048;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HALF + XOP_BYTES + ZOP_BYTES];
-  unsigned char* const xop = smem + 2 * HALF;
-  unsigned char* const zop = xop + XOP_BYTES;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;                  // wave-uniform roles
-  const int tl = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x;
-  const int utt = tile * 32 + tl;
-  const bool live = utt < a.B;
-  const int ur = live ? utt : 0;
-  const bool is_chain = wave < JU;
-  const bool is_conv1 = wave < R32;
-  const int sw = wave - JU;                           // skip tile of a skip wave
-  const int nblocks = a.nblocks;
-
-  // everything this wave needs of block b -> ITS corner of LDS half (b & 1), by LDS-DMA: no registers,
-  // and no cross-wave ordering because a wave only ever reads back what it requested itself
-  auto dma = [&](int b, const WnGenBlock& nb) {
-    unsigned char* buf = smem + (b & 1) * HALF;
-    const f32x4* wd = reinterpret_cast<const f32x4*>(a.ws + nb.w16d_off) + (int64_t)KS0 * JU * 128 + lane;
-#pragma unroll
-    for (int kk = 0; kk < KSR; ++kk)
-#pragma unroll
-      for (int hl = 0; hl < 2; ++hl) {
-        const int blk = (kk * JU + wave) * 2 + hl;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wd + blk * 64),
-                                         (__attribute__((address_space(3))) void*)(buf + blk * 1024), 16, 0, 0);
-      }
-    const f32x4* u0 = reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + (((int64_t)b * gridDim.x + tile) * (JU * 4) + wave * 4) * 64 + lane;
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(u0 + rq * 64),
-                                       (__attribute__((address_space(3))) void*)(buf + U0_OFF + (wave * 4 + rq) * 1024), 16, 0, 0);
-    if (is_conv1) {
-      const f32x4* wr = reinterpret_cast<const f32x4*>(a.ws + nb.w16r_off) + lane;
-#pragma unroll
-      for (int ks = 0; ks < KS2; ++ks)
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-          const int blk = (ks * R32 + wave) * 2 + hl;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wr + blk * 64),
-                                           (__attribute__((address_space(3))) void*)(buf + S::WD_BYTES + blk * 1024), 16, 0, 0);
-        }
-      const float* br = a.params + nb.bias_r_off + min(lane, R - 1);     // one dword per lane: 64 biases
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)br,
-                                       (__attribute__((address_space(3))) void*)(buf + BR_OFF + wave * 256), 4, 0, 0);
-    }
-  };
-  gn_h8 wsk[KS2][2];                                  // skip waves: fragments of the current block
-  auto pre_skip = [&](int b) {
-    const gn_h8* wsi = reinterpret_cast<const gn_h8*>(a.ws + a.skip_w16_off) + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS2; ++ks) {
-      const int64_t blk = ((int64_t)(b * KS2 + ks) * a.skip_tiles + sw) * 2;
-      wsk[ks][0] = wsi[(blk + 0) * 64];
-      wsk[ks][1] = wsi[(blk + 1) * 64];
-    }
-  };
-  // When skip waves exist they issue ALL of block b's LDS-DMA (they are idle most of a block) and publish
-  // it at barrier (3) of block b - 1; the chain waves then neither issue nor wait.  The KiB chunks of a
-  // block are a flat list: gated-conv fragments | conv1 fragments | u0 image | one bias copy per conv1 wave.
-  const int nskip = (int)(blockDim.x >> 6) - JU;
-  const bool dma_by_skip = nskip > 0;
-  auto dma_shared = [&](int b, const WnGenBlock& nb) {
-    unsigned char* buf = smem + (b & 1) * HALF;
-    constexpr int NWD = KSR * JU * 2, NWR = KS2 * R32 * 2, NU0 = JU * 4;
-    const f32x4* wd = reinterpret_cast<const f32x4*>(a.ws + nb.w16d_off) + (int64_t)KS0 * JU * 128 + lane;
-    const f32x4* wr = reinterpret_cast<const f32x4*>(a.ws + nb.w16r_off) + lane;
-    const f32x4* u0 = reinterpret_cast<const f32x4*>(a.ws + a.u0_off) + ((int64_t)b * gridDim.x + tile) * (JU * 4) * 64 + lane;
-    for (int op = sw; op < NWD + NWR + NU0 + R32; op += nskip) {          // wave-uniform
-      if (op < NWD) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wd + op * 64),
-                                         (__attribute__((address_space(3))) void*)(buf + op * 1024), 16, 0, 0);
-      } else if (op < NWD + NWR) {
-        const int c = op - NWD;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wr + c * 64),
-                                         (__attribute__((address_space(3))) void*)(buf + S::WD_BYTES + c * 1024), 16, 0, 0);
-      } else if (op < NWD + NWR + NU0) {
-        const int c = op - NWD - NWR;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(u0 + c * 64),
-                                         (__attribute__((address_space(3))) void*)(buf + U0_OFF + c * 1024), 16, 0, 0);
-      } else {
-        const int c = op - NWD - NWR - NU0;
-        const float* br = a.params + nb.bias_r_off + min(lane, R - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)br,
-                                         (__attribute__((address_space(3))) void*)(buf + BR_OFF + c * 256), 4, 0, 0);
-      }
-    }
-  };
-  // tile of fp32 values (this lane's 16 accumulators = two k-steps) -> hi|lo B operands of k-steps 2j, 2j+1
-  auto put_xop = [&](const f32x16& x, int j) {
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const f32x4 q0 = {x[8 * hf + 0], x[8 * hf + 1], x[8 * hf + 2], x[8 * hf + 3]};
-      const f32x4 q1 = {x[8 * hf + 4], x[8 * hf + 5], x[8 * hf + 6], x[8 * hf + 7]};
-      gn_h8 bh, bl;
-      gn_split8(q0, q1, bh, bl);
-      gn_h8* dst = reinterpret_cast<gn_h8*>(xop + (2 * j + hf) * 2048) + lane;
-      dst[0] = bh;
-      dst[64] = bl;
-    }
-  };
-
-  WnGenBlock cur = a.blocks[0];
-  WnGenBlock nxt = a.blocks[min(1, nblocks - 1)];
-  // `carry`: conv1 waves = the block input / output tile x; skip waves = the skip accumulator tile
-  f32x16 carry;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) carry[r] = 0.f;
-  if (is_chain) {
-    if (!dma_by_skip) dma(0, cur);
-  } else {
-    dma_shared(0, cur);
-    pre_skip(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block 0's LDS image is complete at the barrier below
-  }
-
-  // ---- input causal conv (C_in = 1): the k-ordered fma chain of the fp32 MFMA path, then + bias ----
-  if (is_conv1) {
-    float xs[KS];
-#pragma unroll
-    for (int t = 0; t < KS; ++t) xs[t] = a.xin[(int)((unsigned)((int)a.tau - (KS - 1 - t)) % (unsigned)KS) * a.B + ur];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = 32 * wave + wn_drow(r, h);
-      float acc = 0.f;
-#pragma unroll
-      for (int t = 0; t < KS; ++t) acc = fmaf(a.causal_w[t * R + c], xs[t], acc);
-      carry[r] = acc + a.causal_b[c];
-    }
-    put_xop(carry, wave);
-  }
-  f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;           // gated activations of the previous block (stored late)
-  GN_BARRIER();
-
-  for (int b = 0; b < nblocks; ++b) {
-    const WnGenBlock nn = a.blocks[min(b + 2, nblocks - 1)];
-    unsigned char* const half = smem + (b & 1) * HALF;
-    if (is_chain) {
-      // everything requested at the top of the previous block (block b's fragments, u0, bias; the
-      // stores) is complete.  All of this wave's global traffic is issued HERE, one block before it
-      // is needed, so this wait never sees a fresh request.
-      if (!dma_by_skip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (live) {
-        if (b > 0) {
-          float* zdst = a.ws + a.zrow_off + ((b - 1) * a.B + utt) * D + 16 * wave + 4 * h;
-          *reinterpret_cast<f32x4*>(zdst) = z0;
-          *reinterpret_cast<f32x4*>(zdst + 8) = z1;
-        }
-        if (is_conv1) {                               // this block's input at time tau -> its ring
-          float* dst = a.ws + cur.ring_off + ((int)((unsigned)(int)a.tau % (unsigned)cur.nslots) * a.B + utt) * R + 32 * wave + 4 * h;
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq)
-            *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{carry[4 * rq + 0], carry[4 * rq + 1], carry[4 * rq + 2], carry[4 * rq + 3]};
-        }
-      }
-      if (b + 1 < nblocks && !dma_by_skip) dma(b + 1, nxt);
-      asm volatile("" ::: "memory");
-      // ---- phase A: u tile `wave` = u0 + W_{k-1}^T x ----
-      f32x16 u;
-      f32x4* ub = reinterpret_cast<f32x4*>(half + U0_OFF) + (wave * 4) * 64 + lane;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 v = ub[rq * 64];
-        u[4 * rq + 0] = v.x; u[4 * rq + 1] = v.y; u[4 * rq + 2] = v.z; u[4 * rq + 3] = v.w;
-      }
-      const gn_h8* wl = reinterpret_cast<const gn_h8*>(half) + wave * 128 + lane;
-      const gn_h8* xl = reinterpret_cast<const gn_h8*>(xop) + lane;
-      wn_static_for<KSR>([&](auto kc) {
-        constexpr int kk = decltype(kc)::value;
-        const gn_h8 ah = wl[((kk * JU) * 2 + 0) * 64];
-        const gn_h8 al = wl[((kk * JU) * 2 + 1) * 64];
-        const gn_h8 bh = xl[(kk * 2 + 0) * 64];
-        const gn_h8 bl = xl[(kk * 2 + 1) * 64];
-        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, u, 0, 0, 0);
-        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, u, 0, 0, 0);
-        u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, u, 0, 0, 0);
-      });
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) ub[rq * 64] = f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]};
-    }
-    if (!is_chain && b + 1 < nblocks) dma_shared(b + 1, nxt);    // the other LDS half is free since barrier (3) of b - 1
-    GN_BARRIER();                                     // (1) u tiles visible
-    if (is_chain) {
-      // ---- phase B: z k-step `wave` = channels 16 * wave + {4h.., 8 + 4h..} ----
-      const int jz = wave >> 1, rq0 = 2 * (wave & 1);
-      const f32x4* uf = reinterpret_cast<const f32x4*>(half + U0_OFF) + (jz * 4 + rq0) * 64 + lane;
-      const f32x4* ug = reinterpret_cast<const f32x4*>(half + U0_OFF) + ((jz + D32) * 4 + rq0) * 64 + lane;
-      const f32x4 f0 = uf[0], f1 = uf[64], g0 = ug[0], g1 = ug[64];
-      z0.x = wn_tanh_fast(f0.x) * wn_sigmoid_fast(g0.x); z0.y = wn_tanh_fast(f0.y) * wn_sigmoid_fast(g0.y);
-      z0.z = wn_tanh_fast(f0.z) * wn_sigmoid_fast(g0.z); z0.w = wn_tanh_fast(f0.w) * wn_sigmoid_fast(g0.w);
-      z1.x = wn_tanh_fast(f1.x) * wn_sigmoid_fast(g1.x); z1.y = wn_tanh_fast(f1.y) * wn_sigmoid_fast(g1.y);
-      z1.z = wn_tanh_fast(f1.z) * wn_sigmoid_fast(g1.z); z1.w = wn_tanh_fast(f1.w) * wn_sigmoid_fast(g1.w);
-      gn_h8 bh, bl;
-      gn_split8(z0, z1, bh, bl);
-      gn_h8* zd = reinterpret_cast<gn_h8*>(zop + wave * 2048) + lane;
-      zd[0] = bh;
-      zd[64] = bl;
-    }
-    GN_BARRIER();                                     // (2) z operands visible
-    if (is_conv1) {
-      // ---- phase C: o tile `wave` = b_r + W_r^T z, x_next = o (+ x) ----
-      f32x16 o;
-      const float* bl_ = reinterpret_cast<const float*>(half + BR_OFF + wave * 256) + 32 * wave + 4 * h;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(bl_ + 8 * rq);
-        o[4 * rq + 0] = v.x; o[4 * rq + 1] = v.y; o[4 * rq + 2] = v.z; o[4 * rq + 3] = v.w;
-      }
-      const gn_h8* wl = reinterpret_cast<const gn_h8*>(half + S::WD_BYTES) + wave * 128 + lane;
-      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
-      wn_static_for<KS2>([&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-        const gn_h8 ah = wl[((ks * R32) * 2 + 0) * 64];
-        const gn_h8 al = wl[((ks * R32) * 2 + 1) * 64];
-        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
-        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, o, 0, 0, 0);
-      });
-#pragma unroll
-      for (int r = 0; r < 16; ++r) carry[r] = a.residual ? o[r] + carry[r] : o[r];
-      if (b + 1 < nblocks) put_xop(carry, wave);
-    } else if (!is_chain) {
-      // ---- skip wave: acc += W_{s,b}^T z ----
-      const gn_h8* zl = reinterpret_cast<const gn_h8*>(zop) + lane;
-#pragma unroll
-      for (int ks = 0; ks < KS2; ++ks) {
-        const gn_h8 bh = zl[(ks * 2 + 0) * 64];
-        const gn_h8 bl = zl[(ks * 2 + 1) * 64];
-        carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][1], bh, carry, 0, 0, 0);
-        carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bl, carry, 0, 0, 0);
-        carry = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsk[ks][0], bh, carry, 0, 0, 0);
-      }
-      // block b + 1's LDS image must be complete before barrier (3); the skip fragments requested after it
-      // (2 KS2 loads, vmcnt retires in order) may stay in flight
-      if (b + 1 < nblocks) {
-        pre_skip(b + 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS2) : "memory");
-      }
-    }
-    cur = nxt;
-    nxt = nn;
-    GN_BARRIER();                                     // (3) x operands visible, z operands free
-  }
-  if (is_chain && live) {                             // gated activations of the last block
-    float* zdst = a.ws + a.zrow_off + ((int64_t)(nblocks - 1) * a.B + utt) * D + 16 * wave + 4 * h;
-    *reinterpret_cast<f32x4*>(zdst) = z0;
-    *reinterpret_cast<f32x4*>(zdst + 8) = z1;
-  }
-  // ---- the last block output feeds the head when use_skip is False ----
-  if (a.hrow_off >= 0 && live && is_conv1) {
-    float* dst = a.ws + a.hrow_off + (int64_t)utt * R + 32 * wave + 4 * h;
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
-      *reinterpret_cast<f32x4*>(dst + 8 * rq) = f32x4{carry[4 * rq + 0], carry[4 * rq + 1], carry[4 * rq + 2], carry[4 * rq + 3]};
-  }
-  // ---- folded skip sum + summed biases (the epilogue of the rows contraction it replaces) ----
-  if (!is_chain && live) {
-    const float* bs = a.ws + a.skip_bias_off + 32 * sw + 4 * h;
-    float* dst = a.ws + a.skiprow_off + (int64_t)utt * a.skip_ld + 32 * sw + 4 * h;
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + 8 * rq);
-      *reinterpret_cast<f32x4*>(dst + 8 * rq) =
-          f32x4{wn_act(carry[4 * rq + 0] + bv.x, a.skip_act), wn_act(carry[4 * rq + 1] + bv.y, a.skip_act),
-                wn_act(carry[4 * rq + 2] + bv.z, a.skip_act), wn_act(carry[4 * rq + 3] + bv.w, a.skip_act)};
-    }
-  }
-}
 
 // Chain kernel, second form: weights travel in REGISTERS, several blocks ahead.
 // A kernel starts with a cold L2 (the per-XCD L2s are invalidated at kernel boundaries), so every weight line of a
@@ -1080,6 +793,9 @@ int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s) {
   return WN_OK;
 }
 
+// the chain kernel keeps a copy of the block table and every conv1 bias in LDS: at most this many blocks per launch
+int wn_gen_chain_max_blocks() { return WN_GEN_CHAIN_MAX_BLOCKS; }
+
 int wn_gen_blocks_supported(int R, int D, int KS) {
   if (R == 32 && D == 32) return KS == 2 || KS == 3;
   if (R == 64 && D == 64) return KS == 2;
@@ -1107,22 +823,17 @@ static void gn_launch(const WnGenStepArgs& a, int what, hipStream_t s) {   // wh
   const unsigned gx = (unsigned)((a.B + 31) / 32);
   if (what & 1) hipLaunchKernelGGL((wn_gen_pre_kernel<R32, D32, KS>), dim3(gx, (unsigned)a.nblocks), dim3(64), 0, s, a);
   if (!(what & 2)) return;
-  // knob 23 = 1 or a very deep stack: the first form (weights through an LDS image filled by LDS-DMA)
-  if (wn_debug_get(23) != 1 && a.nblocks <= WN_GEN_CHAIN_MAX_BLOCKS) {
-    WnGenStepArgs a2 = a;
-    a2.ts = wn_debug_get(24) ? wn_gen_ts_buffer() : nullptr;
-    a2.ntiles = (int)gx;
-    // knob 25 = 1: no helper workgroups
-    const unsigned helpers = wn_debug_get(25) == 1 ? 0u : 8u * WN_GEN_HELPERS_PER_XCD;
-    hipLaunchKernelGGL((wn_gen_chain3_kernel<R32, D32, KS>), dim3(gx + helpers), dim3(64 * (2 * D32 + R32 + (a.skip_tiles + 1) / 2)), 0, s, a2);
-  }
-  else
-    hipLaunchKernelGGL((wn_gen_chain_kernel<R32, D32, KS>), dim3(gx), dim3(64 * (2 * D32 + a.skip_tiles)), 0, s, a);
+  WnGenStepArgs a2 = a;
+  a2.ts = wn_debug_get(24) ? wn_gen_ts_buffer() : nullptr;      // knob 24: s_memtime phase stamps (profiling hook)
+  a2.ntiles = (int)gx;
+  const unsigned helpers = 8u * WN_GEN_HELPERS_PER_XCD;         // workgroups that pull the next images into every XCD's L2
+  hipLaunchKernelGGL((wn_gen_chain3_kernel<R32, D32, KS>), dim3(gx + helpers), dim3(64 * (2 * D32 + R32 + (a.skip_tiles + 1) / 2)), 0, s, a2);
 }
 
 // what: 1 = the pre kernel (older taps of every block for time a.tau: reads rings only, so it may run as soon as the
 // chain kernel of time a.tau - 1 has finished), 2 = the chain kernel, 3 = both in order
 int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, int what, hipStream_t s) {
+  if (a.nblocks > WN_GEN_CHAIN_MAX_BLOCKS) { wn_set_error("gen_blocks: more than %d blocks", WN_GEN_CHAIN_MAX_BLOCKS); return WN_E_UNSUPPORTED; }
   if (R == 32 && KS == 2) gn_launch<1, 1, 2>(a, what, s);
   else if (R == 32 && KS == 3) gn_launch<1, 1, 3>(a, what, s);
   else if (R == 64 && KS == 2) gn_launch<2, 2, 2>(a, what, s);

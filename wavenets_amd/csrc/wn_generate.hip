@@ -122,12 +122,6 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   hipStream_t s = (hipStream_t)stream;
   const int RF = wn_plan_receptive_field(p);
   const GenLayout G = gen_layout(p, B, queued != 0);
-  if (wn_debug_get(7) == 1) {                         // knob 7 = 1: print the generation workspace map
-    fprintf(stderr, "gen layout: prime=%lld win0=%lld last=%lld xin=%lld Zrow=%lld skiprow=%lld hrow0=%lld hrow1=%lld dummy=%lld u0=%lld total=%lld\n",
-            (long long)G.prime, (long long)G.win0, (long long)G.last, (long long)G.xin, (long long)G.Zrow, (long long)G.skiprow,
-            (long long)G.hrow0, (long long)G.hrow1, (long long)G.dummy, (long long)G.u0, (long long)G.total);
-    for (size_t b = 0; b < G.ring.size(); ++b) fprintf(stderr, "  ring[%zu]=%lld nslots=%d\n", b, (long long)G.ring[b], G.nslots[b]);
-  }
   if (ws_floats < G.total) { wn_set_error("generate: workspace too small"); return WN_E_INVALID; }
   if (length == 0) return WN_OK;
   float* pws = workspace + G.prime;
@@ -191,22 +185,19 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   // (the fused kernels index rings and rows with 32-bit arithmetic)
   const bool fits32 = (int64_t)(RF + 1) * B * std::max(p->R, p->D) < (1LL << 31) && (int64_t)RF + length < (1LL << 31) &&
                       (int64_t)p->N * B * p->D < (1LL << 31);
-  const bool fused_step = p->fused16_ok && p->LPB == 1 && wn_debug_get(1) != 1 && wn_debug_get(6) != 1 && fits32 &&
-                          wn_gen_blocks_supported(p->R, p->D, p->KS);
+  const bool fused_step = p->fused16_ok && p->LPB == 1 && wn_debug_get(1) != 1 && fits32 &&
+                          wn_gen_blocks_supported(p->R, p->D, p->KS) && p->N <= wn_gen_chain_max_blocks();
   // the folded form (skip sum and the head's first conv as one contraction, as in forward_core): half the columns
   const bool gfold = fold_ok(p);
   const int skipw = gfold ? p->fold_F0 : p->Sh;
   const int64_t skip_img = gfold ? p->frag16_foldF : p->frag16_skipF;
   const size_t first_final = gfold ? 1 : 0;
-  const bool skip_in_chain = fused_step && p->c.use_skip && skip_img >= 0 && wn_gen_skip_fusable(skipw) &&
-                             wn_debug_get(6) != 2;   // knob 6 = 2: skip contraction as its own launch
-  // 128-channel blocks: every block of a step in one launch of wn_gen_chain128_kernel (knob 34 = 1: the streamed forward
-  // kernel per block, = 2: wn_gen_block128_kernel per block)
+  const bool skip_in_chain = fused_step && p->c.use_skip && skip_img >= 0 && wn_gen_skip_fusable(skipw);
+  // 128-channel blocks: every block of a step in one launch of wn_gen_chain128_kernel
   const bool chain128 = !fused_step && p->LPB == 1 && p->Dp == p->D && wn_gen_block128_supported(p->R, p->D, p->KS) &&
-                        !p->blocks.empty() && p->blocks[0].f16nat >= 0 && p->blocks[0].conv1.frag16 >= 0 && wn_debug_get(1) != 1 &&
-                        wn_debug_get(11) == 0 && wn_debug_get(34) == 0 && fits32;
-  // (its folded skip contraction -- 128 columns -- rides in the same launch; knob 6 = 2: its own launch)
-  const bool skip_in_chain128 = chain128 && gfold && p->c.use_skip && skipw == 128 && skip_img >= 0 && wn_debug_get(6) != 2;
+                        !p->blocks.empty() && p->blocks[0].f16nat >= 0 && p->blocks[0].conv1.frag16 >= 0 && wn_debug_get(1) != 1 && fits32;
+  // (its folded skip contraction -- 128 columns -- rides in the same launch)
+  const bool skip_in_chain128 = chain128 && gfold && p->c.use_skip && skipw == 128 && skip_img >= 0;
   if ((fused_step || chain128) && (!p->d_gen || p->gen_B != B || p->gen_chain128 != chain128)) {
     p->gen_chain128 = chain128;
     std::vector<WnGenBlock> tab(p->N);
@@ -234,15 +225,14 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   }
   const int hc0 = (gfold && p->c.use_skip) ? skipw : p->Hin;
   // the whole head in one launch when every layer is one the split-precision rows GEMM would take
-  // (knob 6 = 4: one launch per layer)
-  bool head_fused = fused_step && wn_debug_get(6) != 4 && p->finals.size() > first_final &&
+  bool head_fused = fused_step && p->finals.size() > first_final &&
                     (int)(p->finals.size() - first_final) <= WN_GEN_HEAD_MAX && hc0 % 16 == 0 && hc0 <= 256;
   for (size_t i = first_final; i < p->finals.size(); ++i) {
     const ConvInfo& c = p->finals[i];
     head_fused = head_fused && c.frag16 >= 0 && c.cout % 32 == 0 && c.cout >= 64 && c.cout <= 256 && c.cin % 16 == 0 && c.cin <= 256;
   }
-  // the pre kernel's work of step tau + 1 rides in the head launch of step tau (knob 26 = 1: its own launch)
-  const bool pre_in_head = head_fused && wn_debug_get(26) != 1;
+  // the pre kernel's work of step tau + 1 rides in the head launch of step tau
+  const bool pre_in_head = head_fused;
   WnGenStepArgs ga;
   memset(&ga, 0, sizeof(ga));
   for (int step = 1; step < length; ++step) {
@@ -269,7 +259,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       if (rc) return rc;
     } else {
     // input causal conv on [x[tau-(KS-1)], ..., x[tau]]  ->  block 0's ring slot tau  (128-channel chain: inside its launch)
-    const bool inconv_in_chain = chain128 && p->KS == 2 && wn_debug_get(26) != 1;
+    const bool inconv_in_chain = chain128 && p->KS == 2;
     if (!inconv_in_chain) {
       Gemm g(B, 1, p->R, ceil32(p->R));
       for (int t = 0; t < p->KS; ++t)
@@ -364,11 +354,10 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
         ha.K[l] = c.cin; ha.N[l] = c.cout;
         ha.act[l] = (i + 1 == p->finals.size()) ? WN_ACT_LINEAR : p->c.activation;
       }
-      // categorical heads: the sampling tail and the emit ride in the head launch too (knob 6 = 3: separate kernels)
+      // categorical heads: the sampling tail and the emit ride in the head launch too
       // (up to 8 utterances = one row per wave of the head workgroup: with more, the rows of a wave run one after the other
       // and the tail kernel's one wave per row finishes sooner -- measured 0.074 vs 0.068 ms per step at B = 32)
-      head_tail = p->c.head == WN_HEAD_CATEGORICAL && p->Cout <= 256 && wn_debug_get(6) != 3 && wn_debug_get(27) != 1 &&
-                  (B <= 8 || wn_debug_get(27) == 2);
+      head_tail = p->c.head == WN_HEAD_CATEGORICAL && p->Cout <= 256 && B <= 8;
       if (head_tail) {
         ha.tail = deterministic ? 1 : 2;
         ha.inv_lv = 1.0f / (float)(1 << (p->c.bits - 1));
@@ -399,18 +388,18 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     }
     if (head_tail) {
       // sampled and emitted by the head launch
-    } else if (p->c.head == WN_HEAD_CATEGORICAL && deterministic && wn_debug_get(6) != 3) {
-      // softmax + arg max + emit in one launch (knob 6 = 3: the three separate kernels)
+    } else if (p->c.head == WN_HEAD_CATEGORICAL && deterministic) {
+      // softmax + arg max + emit in one launch
       rc = wn_launch_gen_tail_cat_det(last, B, p->Cout, p->c.bits, out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B, s);
       if (rc) return rc;
     } else {
       // sampler and emit in one launch (categorical draws straight from the logits: the softmax of
       // wn_softmax_kernel in LDS, the class sample_waveform(softmax(logits)) draws)
       const WnEmit em{out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B};
-      if (p->c.head == WN_HEAD_CATEGORICAL && !deterministic && wn_sample_from_logits_supported(p->Cout) && wn_debug_get(6) != 3) {
+      if (p->c.head == WN_HEAD_CATEGORICAL && !deterministic && wn_sample_from_logits_supported(p->Cout)) {
         rc = wn_launch_sample_rand_cat_logits_emit(last, B, p->Cout, p->c.bits, seed, (uint64_t)step, samp, em, s);
         if (rc) return rc;
-      } else if (p->c.head != WN_HEAD_CATEGORICAL && wn_debug_get(6) != 3) {
+      } else if (p->c.head != WN_HEAD_CATEGORICAL) {
         if (deterministic) rc = wn_launch_sample_det_emit(last, B, p->Cout, p->c.num_mixtures, p->c.bits, samp, em, s);
         else rc = wn_launch_sample_rand_emit(last, B, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, seed, (uint64_t)step, samp, em, s);
         if (rc) return rc;

@@ -290,6 +290,7 @@ struct WnGenHeadArgs {
 };
 int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s);
 int wn_gen_blocks_supported(int R, int D, int KS);
+int wn_gen_chain_max_blocks();
 int64_t wn_gen_u0_floats(int B, int nblocks, int D);
 int wn_gen_skip_fusable(int S);
 int wn_launch_gen_blocks(const WnGenStepArgs& a, int R, int KS, int what, hipStream_t s);

@@ -16,7 +16,7 @@
 // that every wave on the chip shares through L1/L2.
 #include "wn_kernels.h"
 
-template <int R32, int D32, int KS, int MINW, int VAR>
+template <int R32, int D32, int KS, int MINW>
 __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs a) {
   constexpr int R = 32 * R32, D = 32 * D32;
   constexpr int JU = 2 * D32;      // row tiles of u
@@ -45,8 +45,7 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
     const float* xrow = (a.xt[tap] ? a.xt[tap] : a.x) + ((int64_t)b * a.T + (xvalid[tap] ? ts : 0)) * R + 4 * h;
 #pragma unroll
     for (int q = 0; q < QR; ++q) {
-      if constexpr (VAR & 16) xq[tap][q] = f32x4{0.1f * q, 0.2f, 0.3f, 0.05f * lane};
-      else xq[tap][q] = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
+      xq[tap][q] = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
     }
   }
 
@@ -96,34 +95,22 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
     if constexpr (st + PD < NS1) {
 #pragma unroll
       for (int j = 0; j < JU; ++j) {
-        if constexpr (VAR & 8) ring[(st + PD) % (PD + 1)][j] = ring[st % (PD + 1)][j];
-        else ring[(st + PD) % (PD + 1)][j] = frd[((st + PD) * JU + j) * 64];
+        ring[(st + PD) % (PD + 1)][j] = frd[((st + PD) * JU + j) * 64];
       }
     }
     // keep the prefetch where it was issued: the scheduler otherwise sinks it next to its use
     __builtin_amdgcn_sched_barrier(0);
     f32x4 xv = xq[tap][q];
     if (!xvalid[tap]) xv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (VAR & 1) {
-      // tile-interleaved order: consecutive MFMAs write different accumulators
+    // tile-interleaved order: consecutive MFMAs write different accumulators
 #pragma unroll
-      for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].x, xv.x, u[j]);
+    for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].x, xv.x, u[j]);
 #pragma unroll
-      for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].y, xv.y, u[j]);
+    for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].y, xv.y, u[j]);
 #pragma unroll
-      for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].z, xv.z, u[j]);
+    for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].z, xv.z, u[j]);
 #pragma unroll
-      for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].w, xv.w, u[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < JU; ++j) {
-        const f32x4 av = ring[st % (PD + 1)][j];
-        u[j] = wn_mfma(av.x, xv.x, u[j]);
-        u[j] = wn_mfma(av.y, xv.y, u[j]);
-        u[j] = wn_mfma(av.z, xv.z, u[j]);
-        u[j] = wn_mfma(av.w, xv.w, u[j]);
-      }
-    }
+    for (int j = 0; j < JU; ++j) u[j] = wn_mfma(ring[st % (PD + 1)][j].w, xv.w, u[j]);
   });
 
   // ---- 1x1 conv weight fragments: start streaming before the (VALU-heavy) gate ----
@@ -147,20 +134,15 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       f32x4 av, gv, zv;
-      if constexpr (VAR & 2) {   // timing-only ablation: no transcendental work
-        av.x = u[j][4 * rq + 0]; gv.x = u[j + D32][4 * rq + 0]; av.y = u[j][4 * rq + 1]; gv.y = u[j + D32][4 * rq + 1];
-        av.z = u[j][4 * rq + 2]; gv.z = u[j + D32][4 * rq + 2]; av.w = u[j][4 * rq + 3]; gv.w = u[j + D32][4 * rq + 3];
-      } else {
       av.x = wn_tanh_fast(u[j][4 * rq + 0]); gv.x = wn_sigmoid_fast(u[j + D32][4 * rq + 0]);
       av.y = wn_tanh_fast(u[j][4 * rq + 1]); gv.y = wn_sigmoid_fast(u[j + D32][4 * rq + 1]);
       av.z = wn_tanh_fast(u[j][4 * rq + 2]); gv.z = wn_sigmoid_fast(u[j + D32][4 * rq + 2]);
       av.w = wn_tanh_fast(u[j][4 * rq + 3]); gv.w = wn_sigmoid_fast(u[j + D32][4 * rq + 3]);
-      }
       zv.x = av.x * gv.x; zv.y = av.y * gv.y; zv.z = av.z * gv.z; zv.w = av.w * gv.w;
       u[j][4 * rq + 0] = zv.x; u[j][4 * rq + 1] = zv.y;
       u[j][4 * rq + 2] = zv.z; u[j][4 * rq + 3] = zv.w;
       const int n0 = 32 * j + 8 * rq + 4 * h;
-      if (tin && !(VAR & 4)) {
+      if (tin) {
         if (a.ag_out) *reinterpret_cast<f32x4*>(a.ag_out + row * D + n0) = gv;
         if (a.z_out) *reinterpret_cast<f32x4*>(a.z_out + row * a.ldz + n0) = zv;
       }
@@ -209,7 +191,7 @@ __global__ __launch_bounds__(256, MINW) void wn_layer_fwd_kernel(WnLayerFwdArgs 
         const f32x4 xr = a.res ? *reinterpret_cast<const f32x4*>(a.res + row * R + n0) : xq[KS - 1][j * 4 + rq];
         ov.x += xr.x; ov.y += xr.y; ov.z += xr.z; ov.w += xr.w;
       }
-      if (!(VAR & 4) || (ov.x == 12345.f)) *reinterpret_cast<f32x4*>(a.x_out + row * R + n0) = ov;
+      *reinterpret_cast<f32x4*>(a.x_out + row * R + n0) = ov;
     }
 }
 
@@ -221,11 +203,8 @@ int wn_layer_fwd_supported(int R, int D, int KS) {
   return 0;
 }
 
-#define WN_LAUNCH_LAYER(R32, D32, KS, MINW)                                                                     \
-  do {                                                                                                         \
-    if (var == 0) hipLaunchKernelGGL((wn_layer_fwd_kernel<R32, D32, KS, MINW, 1>), dim3((unsigned)gx), dim3(256), 0, s, a); \
-    else hipLaunchKernelGGL((wn_layer_fwd_kernel<R32, D32, KS, MINW, 0>), dim3((unsigned)gx), dim3(256), 0, s, a);          \
-  } while (0)
+#define WN_LAUNCH_LAYER(R32, D32, KS, MINW) \
+  hipLaunchKernelGGL((wn_layer_fwd_kernel<R32, D32, KS, MINW>), dim3((unsigned)gx), dim3(256), 0, s, a)
 
 int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s) {
   if (!wn_layer_fwd_supported(a.R, a.D, a.KS)) {
@@ -235,21 +214,9 @@ int wn_launch_layer_fwd(const WnLayerFwdArgs& a, hipStream_t s) {
   const int64_t tiles = (int64_t)a.B * ((a.T + 31) / 32);
   const int64_t gx = (tiles + 3) / 4;
   if (gx <= 0) return WN_OK;
-  const int var = wn_debug_get(0);
   if (a.R == 32) {
     if (a.KS == 2) WN_LAUNCH_LAYER(1, 1, 2, 2);
     else WN_LAUNCH_LAYER(1, 1, 3, 2);
-  } else if (a.R == 64 && a.KS == 2 && var >= 2) {
-    // timing-only ablation builds (tools/time_layer_fwd.py); results are wrong by construction
-#define WN_ABL(V) hipLaunchKernelGGL((wn_layer_fwd_kernel<2, 2, 2, 2, V>), dim3((unsigned)gx), dim3(256), 0, s, a)
-    switch (var) {
-      case 3: WN_ABL(3); break;
-      case 5: WN_ABL(5); break;
-      case 9: WN_ABL(9); break;
-      case 17: WN_ABL(17); break;
-      case 31: WN_ABL(31); break;
-      default: WN_ABL(1); break;
-    }
   } else if (a.R == 64) {
     if (a.KS == 2) WN_LAUNCH_LAYER(2, 2, 2, 2);
     else WN_LAUNCH_LAYER(2, 2, 3, 2);

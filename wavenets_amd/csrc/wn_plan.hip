@@ -153,25 +153,18 @@ int ensure_device_tables(wn_plan* p) {
 // ------------------------------------------------------------------------------------------
 // workspace carving
 
-// The batched weight-gradient path: every dW operand is a whole saved tensor.
-// (round 3: stacks deeper than 1 too -- every conv's input and output gradient is kept, the weight gradients of all
-//  convs of the step are one launch of the generic job table; knob 17 = 1: the per-call path for them)
-bool deferred_wgrad(const wn_plan* p) { return p->LPB == 1 || wn_debug_get(17) != 1; }
-
 // Training passes fold the skip path into the head's first convolution when the plan has the images for it
 // (fold_F0 > 0: depth-1 blocks with skip convs feeding a head whose first conv is narrower than the skip width) and the
-// split-precision kernels run; knob 21 = 1 keeps the reference's two-step form (skip sum, then the head conv).
+// split-precision kernels run (the exact-fp32 mode keeps the reference's two-step form: skip sum, then the head conv).
 // stacks deeper than 1 conv, TRAINING passes only: every conv of the stack on the split-precision kernels
-// (knob 18 = 1: the exact-fp32 composed kernels, as inference and generation run them)
-bool deep16(const wn_plan* p) {
-  return p->deep16_ok && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(17) != 1 && wn_debug_get(18) != 1;
-}
+// (inference and generation run the exact-fp32 composed kernels)
+bool deep16(const wn_plan* p) { return p->deep16_ok && wn_debug_get(1) != 1; }
 
 // The conditioning path works on [B][width] matrices (B = utterances): a rows-GEMM launch per Dense / conv is one wave
 // walking its k-steps behind a global round trip each (30-250 us for a few kFLOP).  They run on the small fp32 product
-// kernel instead (wn_sgemm_small32_kernel: batched over blocks, Dense epilogue); knob 33 = 1: the rows-GEMM launches.
+// kernel instead (wn_sgemm_small32_kernel: batched over blocks, Dense epilogue) when the blocks' tensors are evenly spaced.
 bool cond_small(const wn_plan* p) {
-  if (wn_debug_get(33) == 1 || p->c.cond_inputs <= 0) return false;
+  if (p->c.cond_inputs <= 0) return false;
   for (int b = 1; b < p->N; ++b) {            // the blocks' conditioning convs must be evenly spaced in the flat buffer
     const int64_t w0 = p->tensors[p->blocks[0].conv_cond.kernel_t].off, w1 = p->tensors[p->blocks[1].conv_cond.kernel_t].off;
     if (!p->blocks[b].has_cond || p->tensors[p->blocks[b].conv_cond.kernel_t].off != w0 + (int64_t)b * (w1 - w0)) return false;
@@ -179,16 +172,12 @@ bool cond_small(const wn_plan* p) {
   return p->blocks[0].has_cond;
 }
 
-bool fold_ok(const wn_plan* p) {
-  // (knob 15 = 1 drops the last block's zero output gradient; the folded g_u product has no one-segment form without it)
-  return p->fold_F0 > 0 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 && wn_debug_get(21) != 1 && wn_debug_get(4) != 1 &&
-         wn_debug_get(15) != 1;
-}
+bool fold_ok(const wn_plan* p) { return p->fold_F0 > 0 && wn_debug_get(1) != 1; }
 
 // the head layers' weight gradients run as staged pair jobs when every final layer has a pair kind (widths 128 / 256)
-// in split-precision mode; knob 19 = 1 keeps them on the generic job table
+// in split-precision mode
 bool head_pairs_ok(const wn_plan* p) {
-  if (p->finals.empty() || wn_debug_get(1) == 1 || wn_debug_get(3) == 1 || wn_debug_get(19) == 1) return false;
+  if (p->finals.empty() || wn_debug_get(1) == 1) return false;
   // (folded: the first conv's gradients come from M.)  Layers without a pair kind -- e.g. the 30-column output conv of a
   // mixture head -- stay on the generic job table, on the same compact slab
   for (size_t i = fold_ok(p) ? 1 : 0; i < p->finals.size(); ++i)
@@ -234,7 +223,6 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
   L.loss_rows = cv.take(rows);
   L.yt = cv.take(rows);
   L.sum_scratch = cv.take(2048 + 64);
-  L.GZS = 0;
   L.n_absmax = (int)p->finals.size() + 1 + p->N + (p->N + 1) + p->N * (p->LPB - 1);   // ... | GP[b][i] (deep stacks)
   L.absmax = cv.take(L.n_absmax);
   L.fwd_absmax = cv.take(1);
@@ -257,13 +245,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     L.gxd = cv.take(rows * p->R);
   }
   if (training) {
-    L.g_a = cv.take(rows * maxC);
-    L.g_b = cv.take(rows * maxC);
     L.g_skipsum = cv.take(rows * p->Hin);
-    L.g_h0 = cv.take(rows * hc);
-    L.g_h1 = cv.take(rows * hc);
-    L.g_o = cv.take(rows * p->R);
-    L.g_p = cv.take(p->LPB > 1 ? 2 * rows * p->D : 0);
     int64_t need = 0;
     need = std::max(need, slab_need(B, T, 1, p->R));
     for (const BlockInfo& b : p->blocks) {
@@ -283,61 +265,55 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     L.bslab = 0; L.bsplits = 0;
     L.hslab = 0; L.hsplits = 0; L.head_base = 0; L.head_span = 0;
     L.islab = 0; L.isplits = 0;
-    if (deferred_wgrad(p)) {
-      for (int b = 0; b < p->N; ++b) L.GU.push_back(cv.take(rows * 2 * p->D));
-      // depth > 1: gradient w.r.t. the pre-activation output of every non-gated conv (operand of its weight gradient)
-      L.GP.assign(p->N, std::vector<int64_t>());
-      for (int b = 0; b < p->N; ++b)
-        for (int i = 0; i + 1 < p->LPB; ++i) L.GP[b].push_back(cv.take(rows * p->D));
-      for (int b = 0; b <= p->N; ++b) L.GH.push_back(cv.take(rows * p->R));
-      if (p->S == 0) for (int b = 0; b < p->N; ++b) L.GO.push_back(cv.take(rows * p->R));
-      for (size_t i = 0; i < p->finals.size(); ++i) L.GF.push_back(cv.take(rows * p->finals[i].cout));
-      L.GZS = p->frag16_gzs >= 0 ? cv.take(rows * p->N * p->D) : 0;
-      const int nj = count_jobs(p);
-      int sp = (int)((5000 + (int64_t)nj * B - 1) / ((int64_t)nj * B));
-      const int maxsp = std::max(1, (T + 255) / 256);
-      sp = std::max(1, std::min(sp, maxsp));
-      if (wn_debug_get(10) > 0) sp = std::max(1, std::min(wn_debug_get(10), maxsp));   // knob 10: time splits per utterance
-      L.bsplits = sp;
-      L.bslab = cv.take((int64_t)B * sp * p->nparams);
-      if (p->fold_F0 > 0) {
-        const int64_t pm = (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0;
-        L.mslab = cv.take((int64_t)B * sp * pm);
-        L.mtot = cv.take(pm);
-        L.ytmp = cv.take((int64_t)(p->N * p->D + 1) * p->S);
-      }
-      if (wn_inconv_wgrad_supported(p->R, p->KS) && p->tensors[p->causal.kernel_t].off == 0 &&
-          p->tensors[p->causal.bias_t].off == (int64_t)p->KS * p->R) {
-        L.isplits = std::max(1, std::min((512 + B - 1) / B, std::max(1, T / 64)));
-        L.islab = cv.take((int64_t)B * L.isplits * (p->KS + 1) * p->R);
-      }
-      // The head's few products (4-8 jobs each) cannot fill the chip at the blocks' split count (one wave per
-      // SIMD with one chunk of look-ahead is latency bound): ~1.5 waves per SIMD for them.  Measured at
-      // configs[1] (same-process sweep, ms per step): shared 7.64 | 8 splits 7.68 | 12: 7.57 | 16: 7.71 |
-      // 24: 7.63 | 32: 7.67 | 48: 7.71 -- a shallow, irregular optimum.
-      // knob 0 = -1: share the blocks' slab and split count; > 0: that many splits
-      if (!p->finals.empty() && wn_debug_get(0) >= 0) {
-        int njh = 0;
-        for (const ConvInfo& c : p->finals) njh += jobs_for(c.cin, c.cout);
-        int hs = (int)((1536 + (int64_t)njh * B - 1) / ((int64_t)njh * B));
-        // pair jobs: one workgroup per (layer, utterance, time range) -> about one workgroup per CU and layer
-        if (head_pairs_ok(p)) hs = std::max(1, (256 + B - 1) / B);
-        if (wn_debug_get(0) > 0) hs = wn_debug_get(0);
-        hs = std::max(sp, std::min(hs, maxsp));
-        if (hs > sp) {
-          L.head_base = p->tensors[p->finals.front().kernel_t].off;
-          const TensorInfo& last = p->tensors[p->finals.back().bias_t];
-          L.head_span = last.off + last.len - L.head_base;
-          L.hsplits = hs;
-          L.hslab = cv.take((int64_t)B * hs * L.head_span);
-        }
+    for (int b = 0; b < p->N; ++b) L.GU.push_back(cv.take(rows * 2 * p->D));
+    // depth > 1: gradient w.r.t. the pre-activation output of every non-gated conv (operand of its weight gradient)
+    L.GP.assign(p->N, std::vector<int64_t>());
+    for (int b = 0; b < p->N; ++b)
+      for (int i = 0; i + 1 < p->LPB; ++i) L.GP[b].push_back(cv.take(rows * p->D));
+    for (int b = 0; b <= p->N; ++b) L.GH.push_back(cv.take(rows * p->R));
+    if (p->S == 0) for (int b = 0; b < p->N; ++b) L.GO.push_back(cv.take(rows * p->R));
+    for (size_t i = 0; i < p->finals.size(); ++i) L.GF.push_back(cv.take(rows * p->finals[i].cout));
+    const int nj = count_jobs(p);
+    int sp = (int)((5000 + (int64_t)nj * B - 1) / ((int64_t)nj * B));
+    const int maxsp = std::max(1, (T + 255) / 256);
+    sp = std::max(1, std::min(sp, maxsp));
+    L.bsplits = sp;
+    L.bslab = cv.take((int64_t)B * sp * p->nparams);
+    if (p->fold_F0 > 0) {
+      const int64_t pm = (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0;
+      L.mslab = cv.take((int64_t)B * sp * pm);
+      L.mtot = cv.take(pm);
+      L.ytmp = cv.take((int64_t)(p->N * p->D + 1) * p->S);
+    }
+    if (wn_inconv_wgrad_supported(p->R, p->KS) && p->tensors[p->causal.kernel_t].off == 0 &&
+        p->tensors[p->causal.bias_t].off == (int64_t)p->KS * p->R) {
+      L.isplits = std::max(1, std::min((512 + B - 1) / B, std::max(1, T / 64)));
+      L.islab = cv.take((int64_t)B * L.isplits * (p->KS + 1) * p->R);
+    }
+    // The head's few products (4-8 jobs each) cannot fill the chip at the blocks' split count (one wave per
+    // SIMD with one chunk of look-ahead is latency bound): ~1.5 waves per SIMD for them.  Measured at
+    // configs[1] (same-process sweep, ms per step): shared 7.64 | 8 splits 7.68 | 12: 7.57 | 16: 7.71 |
+    // 24: 7.63 | 32: 7.67 | 48: 7.71 -- a shallow, irregular optimum.
+    if (!p->finals.empty()) {
+      int njh = 0;
+      for (const ConvInfo& c : p->finals) njh += jobs_for(c.cin, c.cout);
+      int hs = (int)((1536 + (int64_t)njh * B - 1) / ((int64_t)njh * B));
+      // pair jobs: one workgroup per (layer, utterance, time range) -> about one workgroup per CU and layer
+      if (head_pairs_ok(p)) hs = std::max(1, (256 + B - 1) / B);
+      hs = std::max(sp, std::min(hs, maxsp));
+      if (hs > sp) {
+        L.head_base = p->tensors[p->finals.front().kernel_t].off;
+        const TensorInfo& last = p->tensors[p->finals.back().bias_t];
+        L.head_span = last.off + last.len - L.head_base;
+        L.hsplits = hs;
+        L.hslab = cv.take((int64_t)B * hs * L.head_span);
       }
     }
   } else {
     L.bslab = 0; L.bsplits = 0;
     L.hslab = 0; L.hsplits = 0; L.head_base = 0; L.head_span = 0;
     L.islab = 0; L.isplits = 0;
-    L.g_a = L.g_b = L.g_skipsum = L.g_h0 = L.g_h1 = L.g_o = L.g_p = L.slab = 0;
+    L.g_skipsum = L.slab = 0;
     L.slab_floats = 0;
   }
   L.total = cv.pos;
@@ -558,17 +534,6 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
       if (bi.has_skip) add_piece16(p, bi.g16u, p->D, p->tensors[bi.conv_skip.kernel_t].off, p->S, p->S, 0, p->R / 16);
     }
   }
-  if (p->LPB == 1 && p->c.use_skip && p->S > 0 && m32(p->D) && m16(p->S) && m16(p->R) && p->Dp == p->D) {
-    // W_s g_skip for ALL blocks in one contraction (g_skip is shared): image rows b*D.. = W_s of block b
-    p->frag16_gzs = new_image16(p, p->N * p->D, p->S);
-    for (int b = 0; b < p->N; ++b) {
-      BlockInfo& bi = p->blocks[b];
-      add_piece16(p, p->frag16_gzs, p->D, p->tensors[bi.conv_skip.kernel_t].off, p->S, p->S, 0, 0, b * (p->D / 32),
-                  p->N * p->D / 32);
-      bi.g16r = new_image16(p, p->D, p->R);
-      add_piece16(p, bi.g16r, p->D, p->tensors[bi.conv1.kernel_t].off, p->R, p->R, 0, 0);
-    }
-  }
   // skip path folded into the head's first conv: needs skip convs feeding a head with >= 1 hidden layer narrower than S
   if (p->LPB == 1 && p->c.use_skip && p->S > 0 && p->finals.size() >= 2 && p->finals[0].cout < p->S && m32(p->finals[0].cout) &&
       m32(p->D) && p->D % 64 == 0 && m16(p->R) && m16(p->S) && p->Dp == p->D && p->frag16_skipF >= 0 &&
@@ -780,39 +745,34 @@ extern "C" int wn_plan_describe(const wn_plan* p, char* buf, int32_t len) {
   if (p->LPB > 1 && deep16(p)) fwd = "per conv of the stack, split precision in training passes (rows contractions + the fused block kernel for the gated conv)";
   else if (p->LPB > 1) fwd = "composed per conv (rows GEMM fp32 + fused fp32 kernel for the gated conv where the shape allows)";
   else if (!exact && p->fused16_ok) fwd = "fused split-precision block kernel, weights LDS-resident (wn_layer_fwd_f16_kernel)";
-  else if (!exact && !p->blocks.empty() && p->blocks[0].f16nat >= 0 && wn_debug_get(11) == 0)
+  else if (!exact && !p->blocks.empty() && p->blocks[0].f16nat >= 0)
     fwd = "fused split-precision block kernel, weights streamed through an LDS ring (wn_layer_fwd_s128_kernel)";
-  else if (!exact && !p->blocks.empty() && p->blocks[0].f16gate >= 0 && wn_debug_get(11) != 1)
+  else if (!exact && !p->blocks.empty() && p->blocks[0].f16gate >= 0)
     fwd = "two split-precision contractions per block (gated conv + gate, 1x1 + residual)";
   else if (p->fused_ok) fwd = "fused exact-fp32 block kernel (wn_layer_fwd_kernel)";
   else fwd = "composed: rows GEMM -> gate kernel -> rows GEMM";
   const bool fold = fold_ok(p);
-  const bool deferred = deferred_wgrad(p);
   const char* bwd;
-  if (!deferred) bwd = "per-block composed backward with per-call weight gradients (layers_per_block > 1)";
-  else if (p->LPB > 1) bwd = "per-block composed backward, one rows contraction per conv of the stack (layers_per_block > 1)";
-  else if (fold && p->N >= 2 && wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1)
+  if (p->LPB > 1) bwd = "per-block composed backward, one rows contraction per conv of the stack (layers_per_block > 1)";
+  else if (fold && p->N >= 2 && wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D)
     bwd = "two products per launch (wn_bwd_pair_kernel: g_x(b+1) and g_u(b))";
-  else if (fold && p->N >= 2 && wn_bwd_s128_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D && wn_debug_get(22) != 1)
+  else if (fold && p->N >= 2 && wn_bwd_s128_supported(p->R, p->D, p->KS, p->fold_F0) && p->Dp == p->D)
     bwd = "two products per launch, weights streamed through an LDS ring (wn_bwd_s128_kernel: g_x(b+1) and g_u(b))";
   else if (!exact) bwd = "two split-precision rows contractions per block (g_u with the gate derivative, g_x)";
   else bwd = "two exact-fp32 rows contractions per block";
   const char* wg;
-  if (!deferred) wg = "per-call split-K products (wn_wgrad_kernel) + reduces";
-  else if (p->LPB > 1 && deep16(p) && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(8) != 1)
+  if (p->LPB > 1 && deep16(p) && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R)
     wg = "one workgroup per (conv, utterance, time range): the last conv + 1x1 of a block as for depth 1, inner convs through the kernel's INNER form (wn_wgrad_layer_kernel)";
   else if (p->LPB > 1 && deep16(p)) wg = "generic batched job table, split precision, every conv of every stack in one launch (wn_wgrad_batched_kernel)";
   else if (p->LPB > 1) wg = "generic batched job table in exact fp32, every conv of every stack in one launch (wn_wgrad_batched_kernel)";
-  else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(8) != 1 && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R)
+  else if (!exact && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R)
     wg = "one workgroup per (block, utterance, time range) for dW_d, db_d, dW_r, db_r (wn_wgrad_layer_kernel)";
-  else if (!exact && wn_debug_get(3) != 1 && wn_debug_get(13) != 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D &&
+  else if (!exact && p->KS == 2 && p->R == p->D && p->Dp == p->D &&
            wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 && wn_wgrad_pair_kind(p->D, p->R) == 2)
-    wg = wn_debug_get(16) == 1 || wn_debug_get(16) == 2
-             ? "staged pair jobs (wn_wgrad_pair_kernel)"
-             : (wn_debug_get(16) == 0 && fold && p->fold_F0 == 128 && p->D == 128
-                    ? "two jobs per block on transposed LDS reads: both taps of dW_d from one read of du; dW_r together with the "
-                      "folded skip path's M = Z^T dL/da from one read of z (wn_wgrad_tr_kernel)"
-                    : "two jobs per block on transposed LDS reads: both taps of dW_d from one read of du; dW_r (wn_wgrad_tr_kernel)");
+    wg = (fold && p->fold_F0 == 128 && p->D == 128)
+             ? "two jobs per block on transposed LDS reads: both taps of dW_d from one read of du; dW_r together with the "
+               "folded skip path's M = Z^T dL/da from one read of z (wn_wgrad_tr_kernel)"
+             : "two jobs per block on transposed LDS reads: both taps of dW_d from one read of du; dW_r (wn_wgrad_tr_kernel)";
   else wg = "generic batched job table (wn_wgrad_batched_kernel)";
   snprintf(buf, (size_t)len,
            "math: %s | block forward: %s | skip path: %s | backward data: %s | block weight gradients: %s",

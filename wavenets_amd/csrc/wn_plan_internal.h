@@ -42,7 +42,6 @@ struct BlockInfo {
   ConvInfo conv1, conv_skip, conv_cond;
   bool has_skip = false, has_cond = false;
   int64_t g16u = -1;    // fp16 split image [W_r | W_s] (backward: d z) or -1
-  int64_t g16r = -1;    // fp16 split image [W_r] alone (used with the precomputed W_s g_skip slice) or -1
   int64_t f16gate = -1; // fp16 split image of the gated conv with row tiles ordered [f f g g] per 64 channels, or -1
   int64_t f16nat = -1;  // fp16 split image of the gated conv in natural row-tile order for the streamed one-kernel forward (R = D = 128), or -1
   int64_t g16uf = -1;   // fp16 split image [W_r | V(b)], V(b) = W_s(b) W_f0 (skip path folded into the first head conv), or -1
@@ -68,7 +67,6 @@ struct wn_plan {
   // A[N*2D][Cc], backward image A[Cc][N*2D]; -1 = per-block path
   int64_t frag_condF = -1, frag_condB = -1;
   int64_t frag16_skipF = -1;   // the same as an fp16 split image, or -1
-  int64_t frag16_gzs = -1;     // fp16 split image A[N*D][S]: rows b*D.. = W_s of block b (backward of the folded skip sum)
   int64_t frag_floats = 0;
   // skip path folded into the head's first convolution (training passes; see wn_skip_fold_kernel): F0 = its width,
   // forward image A[F0][N*D] of V^T.  prep2 = pieces whose SOURCE is the workspace (the V matrix), not the parameters
@@ -108,7 +106,6 @@ struct wn_plan {
   bool jobs_mfused = false;             // M = Z^T dL/da of the folded skip path rides in the dW_r jobs
   bool jobs_deep16 = false;             // inner gradients of deeper stacks carry max-abs slots (split-precision job kernel)
   int jobs_mtr = 0;                     // ... or is its own transposed-read launch over several blocks' z (kind 7 / 8; pairs index 0)
-  int jobs_pair_mode = 0;               // 0: one job per tap, 1: staged both-taps job, 2: transposed-read both-taps job
   // the head layers' weight gradients as staged pair jobs (kinds 1..4) on the head's own time split
   int hpair_first[6] = {0, 0, 0, 0, 0, 0}, hpair_count[6] = {0, 0, 0, 0, 0, 0};
   bool jobs_headpairs = false;
@@ -159,11 +156,7 @@ struct WsLayout {
   std::vector<int64_t> HA;              // head activations
   int64_t logits, probs;
   int64_t target, loss_rows, yt;
-  int64_t g_a, g_b;                     // head gradient ping-pong [rows][maxC]
   int64_t g_skipsum;                    // [rows][Hin]
-  int64_t g_h0, g_h1;                   // [rows][max(R,D)]
-  int64_t g_o;                          // [rows][R]
-  int64_t g_p;                          // [rows][D] (depth > 1)
   int64_t slab, slab_floats;
   std::vector<int64_t> GU, GH, GO, GF;  // deferred-wgrad mode: per-block g_u, g_h (N+1), g_o; per-final g
   int64_t bslab; int bsplits;           // batched slab [B*bsplits][nparams]
@@ -177,7 +170,6 @@ struct WsLayout {
   // ([N*D + 1][S]), the slab [B*bsplits][N*D*F0 + F0] of M = Z^T dL/da with the column sums behind it, its reduced
   // form [M; colsum] and Y = [M; colsum] W_f0^T ([N*D + 1][S])
   int64_t vfold, bfold, wsall, mslab, mtot, ytmp;
-  int64_t GZS;                          // [rows][N*D] precomputed W_s g_skip of every block, or 0
   std::vector<int64_t> XD;              // dropout: dropped copy of every block input (training)
   int64_t gxd;                          // dropout: scratch for d loss / d (dropped input)
   int64_t absmax; int n_absmax;         // running max-abs scalars: GF[i] | g_skipsum | GU[b] | GH[b] | GP[b][i]
@@ -268,7 +260,6 @@ struct BlockPtrs {
   bool fused;
   const float* F16d; const float* F16r;   // fp16 split images of the gated conv / conv1, or null
   const float* G16u; const float* G16x;   // fp16 split images of the backward-data products, or null
-  const float* G16r;                      // [W_r] alone
   const float* G16uf;                     // [W_r | V(b)]: skip path folded into the first head conv (training), or null
   const float* F16g;                      // gated conv, row tiles [f f g g] per 64 channels (composed split-precision forward), or null
   const float* F16n;                      // gated conv, natural row-tile order, for the streamed one-kernel forward (R = D = 128), or null
@@ -309,7 +300,6 @@ struct BlockGrads {
   const float* am_gxout; const float* am_gskip;   // running max-abs of g_xout / g_skip (or null)
   float* am_gu; float* am_gx;                      // where to publish max-abs of g_u / g_x (or null)
   float* am_gp[16];                                // ... of the kept inner gradients g_pi[i] (deep stacks in training), or null
-  const float* gzs; int ld_gzs;                    // precomputed W_s g_skip slice of this block, or null
   const float* g_fold; int fold_F0; const float* am_gfold;   // folded skip path: dL/da of the first head conv [rows][F0] replaces g_skip
   float drop_rate; uint32_t drop_key; float* g_xd;  // dropout on the block input: mask the conv-path gradient
 };
@@ -330,7 +320,6 @@ inline bool m32(int v) { return v >= 64 && v % 32 == 0; }
 // ---- wn_plan.hip ----
 int ensure_device_tables(wn_plan* p);
 WsLayout make_layout(const wn_plan* p, int B, int T, bool training);
-bool deferred_wgrad(const wn_plan* p);
 bool deep16(const wn_plan* p);
 bool cond_small(const wn_plan* p);
 bool fold_ok(const wn_plan* p);

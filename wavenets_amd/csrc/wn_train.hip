@@ -22,42 +22,33 @@ void add_jobs(std::vector<WnWgJob>& jobs, int64_t x_off, int ldx, int K, int shi
 
 // the dedicated skip weight-gradient kernel applies to the split-precision path with uniform blocks
 bool skip_kernel_ok(const wn_plan* p) {
-  return p->c.use_skip && p->S > 0 && p->Dp == p->D && p->N >= 1 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
-         wn_debug_get(5) != 1 && wn_wgrad_skip_supported(p->D, p->S, p->N * p->D);
+  return p->c.use_skip && p->S > 0 && p->Dp == p->D && p->N >= 1 && wn_debug_get(1) != 1 &&
+         wn_wgrad_skip_supported(p->D, p->S, p->N * p->D);
 }
 
 int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool skipk = skip_kernel_ok(p);
-  // knob 8 = 1 keeps the per-block weight gradients on the generic job table
-  // (stacks deeper than 1 in split-precision training, deep16: the last conv + the 1x1 as for depth 1, every inner conv
-  // through the kernel's INNER form)
-  const bool layerk = (p->LPB == 1 || deep16(p)) && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1 &&
-                      wn_debug_get(3) != 1 && wn_debug_get(8) != 1;
-  // knob 13 = 1 keeps them on the generic job table
+  // 32 / 64-channel blocks: one workgroup per (block, utterance, time range) (wn_wgrad_layer.hip; stacks deeper than 1 in
+  // split-precision training, deep16: the last conv + the 1x1 as for depth 1, every inner conv through the kernel's INNER
+  // form); other shapes stay on the generic job table
+  const bool layerk = (p->LPB == 1 || deep16(p)) && wn_wgrad_layer_supported(p->R, p->D, p->KS) && p->Dp == p->R && wn_debug_get(1) != 1;
+  // 128-channel blocks: two transposed-LDS-read jobs per block (wn_wgrad_tr.hip): both taps of the gated conv against ONE
+  // read of du; dW_r
   const bool pairk = !layerk && p->LPB == 1 && p->KS == 2 && p->R == p->D && p->Dp == p->D && wn_wgrad_pair_kind(p->R, 2 * p->D) == 1 &&
-                     wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1 && wn_debug_get(3) != 1 &&
-                     wn_debug_get(13) != 1;
-  // Both taps of a block's gated conv as ONE job (du read once): by the transposed-LDS-read kernel (wn_wgrad_tr.hip,
-  // default); knob 16 = 1: one staged job per tap (du read twice); = 2: the staged kernel with both taps (128 accumulator
-  // registers beside its staging registers: spills, 22.1 vs 16.4 ms per step at configs[3])
-  const int pair_mode = !pairk ? 0 : (wn_debug_get(16) == 1 ? 0 : (wn_debug_get(16) == 2 ? 1 : 2));
-  const bool pair_dual = pair_mode != 0;
-  // with the transposed-read kernels the folded skip path's M = Z^T dL/da is computed by the dW_r jobs (knob 16 = 3: own kernel)
-  // ... and by the per-block kernel of 32 / 64-channel blocks, which stages z anyway (wn_wgrad_layer_kernel<.., true>)
-  const bool mfused = pair_mode == 2 && p->D == 128 && fold_ok(p) && p->fold_F0 == 128 && p->Dp == p->D && p->S > 0 &&
-                      wn_debug_get(16) != 3;
+                     wn_wgrad_pair_kind(p->D, p->R) == 2 && wn_debug_get(1) != 1;
+  // ... whose dW_r jobs also compute the folded skip path's M = Z^T dL/da (one read of z)
+  const bool mfused = pairk && p->D == 128 && fold_ok(p) && p->fold_F0 == 128 && p->Dp == p->D && p->S > 0;
   // 64- / 32-channel blocks: M as transposed-read jobs over the z of four / eight blocks at a time against one read of
-  // dL/da (wn_wgrad_tr kinds 7 / 8; knob 16 = 3: wn_wgrad_skip_kernel)
-  const int mtr = (layerk && fold_ok(p) && p->fold_F0 == 128 && p->Dp == p->D && p->S > 0 && wn_debug_get(16) != 3)
+  // dL/da (wn_wgrad_tr kinds 7 / 8); other widths: wn_wgrad_skip_kernel
+  const int mtr = (layerk && fold_ok(p) && p->fold_F0 == 128 && p->Dp == p->D && p->S > 0)
                       ? (p->D == 64 ? 7 : (p->D == 32 ? 8 : 0)) : 0;
   const bool fold = fold_ok(p);
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
-  // knob 20 = 1 keeps the input conv's weight gradients on the generic job table
-  const bool inconvk = L.isplits > 0 && wn_debug_get(20) != 1;
+  const bool inconvk = L.isplits > 0;
   const bool d16 = deep16(p);
   if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
       p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_pair_mode == pair_mode && p->jobs_mfused == mfused && p->jobs_mtr == mtr && p->jobs_deep16 == d16 && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
+      p->jobs_pairk == pairk && p->jobs_mfused == mfused && p->jobs_mtr == mtr && p->jobs_deep16 == d16 && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
   std::vector<WnWgLayer> wgl, wgli;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
@@ -107,22 +98,13 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       wgl.push_back(w);
     } else if (pairk) {
       const int64_t xoff = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
-      if (pair_dual) {
-        // both taps in one job: x[t - d] | x[t] against ONE read of du (kind 6)
+      {
+        // both taps in one job: x[t - d] | x[t] against ONE read of du
         WnWgPair w;
         memset(&w, 0, sizeof(w));
         w.x_off = xoff; w.g_off = L.GU[b]; w.shift = c.dil;
         w.w_off = p->tensors[c.kernel_t].off;
         w.b_off = p->tensors[c.bias_t].off;
-        w.gmax_off = am_GU(b);
-        pairs[1].push_back(w);
-      } else
-      for (int t = 0; t < p->KS; ++t) {
-        WnWgPair w;
-        memset(&w, 0, sizeof(w));
-        w.x_off = xoff; w.g_off = L.GU[b]; w.shift = (p->KS - 1 - t) * c.dil;
-        w.w_off = p->tensors[c.kernel_t].off + (int64_t)t * p->R * 2 * p->D;
-        w.b_off = t == p->KS - 1 ? p->tensors[c.bias_t].off : -1;
         w.gmax_off = am_GU(b);
         pairs[1].push_back(w);
       }
@@ -242,7 +224,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_pair_mode = pair_mode; p->jobs_mfused = mfused; p->jobs_mtr = mtr; p->jobs_deep16 = d16; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
+  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_mfused = mfused; p->jobs_mtr = mtr; p->jobs_deep16 = d16; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
   p->jobs_fold = fold;
   p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
   p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
@@ -250,129 +232,100 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   return WN_OK;
 }
 
-}  // namespace
+// ------------------------------------------------------------------------------------------
+// One call of wn_train_fwd_bwd: the caller's buffers, the workspace layout of (B, T) and the running max-abs slots of the
+// gradient tensors; the phases of the step are its member functions, in launch order.
+// ------------------------------------------------------------------------------------------
+struct TrainCall {
+  wn_plan* p; const float* params; const float* x_full; const float* cond;
+  int B, T, global_batch, n_replicas;
+  float* grads; float* loss_out; float* pred_out; float* ws; hipStream_t s;
+  WsLayout L;
+  int64_t rows;
+  float* inputs;
+  const float* fragbase; float* slab;
+  // running max-abs scalars of the gradient tensors (operand scaling of the split-precision GEMMs): GF[i] | g_skipsum | GU[b] | GH[b] | GP[b][i]
+  float* am; int nf; float* am_gskip;
+  const float* mlast = nullptr;      // the mapped condition (input of every conv_cond)
+  bool fold = false, cond_batched = false;
+  float* am_GF(int i) const { return am + i; }
+  float* am_GU(int b) const { return am + nf + 1 + b; }
+  float* am_GH(int b) const { return am + nf + 1 + p->N + b; }
+  float* am_GP(int b, int i) const { return am + nf + 1 + p->N + (p->N + 1) + b * (p->LPB - 1) + i; }
 
-extern "C" int wn_plan_set_train_phases(wn_plan* p, int32_t phases) {
-  if (!p || phases < 1 || phases > 3) { wn_set_error("set_train_phases: 1 (forward + loss), 2 (backward), 3 (both)"); return WN_E_INVALID; }
-  p->train_phases = phases;
-  return WN_OK;
-}
-
-extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_full, const float* cond,
-                                int32_t B, int32_t T, int32_t global_batch, int32_t n_replicas, float* grads,
-                                float* loss_out, float* pred_out, float* workspace, int64_t ws_floats,
-                                void* stream) {
-  if (!p || !params || !x_full || !workspace || !loss_out || !grads || B < 1 || T < 1) { wn_set_error("train_fwd_bwd: bad arguments"); return WN_E_INVALID; }
-  hipStream_t s = (hipStream_t)stream;
-  const WsLayout L = make_layout(p, B, T, true);
-  if (ws_floats < L.total) { wn_set_error("train_fwd_bwd: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)L.total); return WN_E_INVALID; }
-  if (global_batch <= 0) global_batch = B;
-  if (n_replicas <= 0) n_replicas = 1;
-  float* ws = workspace;
-  const int64_t rows = (int64_t)B * T;
-  float* inputs = ws + L.probs;
-  // A caller may run the step as two calls (wn_plan_set_train_phases 1, then 2) and queue work of its own in between --
-  // the Python mirror reads the loss and the metrics back from there, 4 ms before the step ends.  Everything the second
-  // half needs lives in the workspace.
-  const int phases = p->train_phases;
-  int rc = WN_OK;
-  if (phases & 1) {
-  { const int rcs = shift_split(x_full, B, T, inputs, ws + L.yt, s); if (rcs) return rcs; }
-  if (p->phase_on) (void)hipEventRecord(p->phase_ev[0], s);
-  rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
-  if (rc) return rc;
-  if (p->phase_on) (void)hipEventRecord(p->phase_ev[1], s);
-  }
-  // running max-abs scalars of the gradient tensors (operand scaling of the split-precision GEMMs)
-  float* am = ws + L.absmax;
-  const int nf = (int)p->finals.size();
-  auto am_GF = [&](int i) { return am + i; };
-  float* am_gskip = am + nf;
-  auto am_GU = [&](int b) { return am + nf + 1 + b; };
-  auto am_GH = [&](int b) { return am + nf + 1 + p->N + b; };
-  auto am_GP = [&](int b, int i) { return am + nf + 1 + p->N + (p->N + 1) + b * (p->LPB - 1) + i; };
-  if (phases & 1) {
-  WN_HIP_CHECK(hipMemsetAsync(am, 0, L.n_absmax * sizeof(float), s));
-  rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s);
-  if (rc) return rc;
-  if (pred_out) {
-    if (p->c.head == WN_HEAD_CATEGORICAL) rc = wn_launch_softmax(ws + L.logits, pred_out, rows, p->Cout, s);
-    else rc = hipMemcpyAsync(pred_out, ws + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
+  // ---- forward + loss (+ the armed step sample, the L2 loss term, the range flag): src/model.py:319-334 ----
+  int forward_and_loss() {
+    int rc;
+    { const int rcs = shift_split(x_full, B, T, inputs, ws + L.yt, s); if (rcs) return rcs; }
+    if (p->phase_on) (void)hipEventRecord(p->phase_ev[0], s);
+    rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
     if (rc) return rc;
-  }
-  if (p->step_sample) {
-    // sample_waveform(pred) of this step (src/model.py:338) drawn from the logits while they are still hot:
-    // no (rows, C) probability tensor is written or re-read
-    float* so = p->step_sample;
-    p->step_sample = nullptr;
-    if (p->c.head == WN_HEAD_CATEGORICAL) {
-      if (p->step_sample_det) {
-        wn_set_error("step sample: deterministic categorical draws go through wn_sample_waveform");
-        return WN_E_UNSUPPORTED;
-      }
-      rc = wn_launch_sample_rand_cat_logits(ws + L.logits, rows, p->Cout, p->c.bits, p->step_sample_seed, p->step_sample_off, so, s);
-    } else {
-      // mixture heads: the model output IS the logits tensor
-      if (p->step_sample_det) rc = wn_launch_sample_det(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, so, s);
-      else rc = wn_launch_sample_rand(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, p->step_sample_seed, p->step_sample_off, so, s);
+    if (p->phase_on) (void)hipEventRecord(p->phase_ev[1], s);
+    WN_HIP_CHECK(hipMemsetAsync(am, 0, L.n_absmax * sizeof(float), s));
+    rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s);
+    if (rc) return rc;
+    if (pred_out) {
+      if (p->c.head == WN_HEAD_CATEGORICAL) rc = wn_launch_softmax(ws + L.logits, pred_out, rows, p->Cout, s);
+      else rc = hipMemcpyAsync(pred_out, ws + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
+      if (rc) return rc;
     }
+    if (p->step_sample) {
+      // sample_waveform(pred) of this step (src/model.py:338) drawn from the logits while they are still hot:
+      // no (rows, C) probability tensor is written or re-read
+      float* so = p->step_sample;
+      p->step_sample = nullptr;
+      if (p->c.head == WN_HEAD_CATEGORICAL) {
+        if (p->step_sample_det) {
+          wn_set_error("step sample: deterministic categorical draws go through wn_sample_waveform");
+          return WN_E_UNSUPPORTED;
+        }
+        rc = wn_launch_sample_rand_cat_logits(ws + L.logits, rows, p->Cout, p->c.bits, p->step_sample_seed, p->step_sample_off, so, s);
+      } else {
+        // mixture heads: the model output IS the logits tensor
+        if (p->step_sample_det) rc = wn_launch_sample_det(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, so, s);
+        else rc = wn_launch_sample_rand(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, p->step_sample_seed, p->step_sample_off, so, s);
+      }
+      if (rc) return rc;
+    }
+    // the step's other two scalars are complete here too: the L2 regulariser's loss term (src/model.py:331-334) and the
+    // range flag of the forward pass
+    if (p->c.l2_reg_factor > 0.f) {
+      float* norms = ws + L.loss_rows;   // free by now
+      rc = wn_launch_sumsq(params, p->d_kdesc, (int)p->kdesc.size(), norms, s);
+      if (rc) return rc;
+      rc = wn_launch_sum(norms, (int64_t)p->kdesc.size(), p->c.l2_reg_factor / (float)n_replicas, loss_out + 1, ws + L.sum_scratch, s);
+      if (rc) return rc;
+    } else {
+      rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
+      if (rc) return rc;
+    }
+    // (with dropout the split kernels read H * mask / (1 - rate) while only H is published: compare against limit * (1 - rate))
+    rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT * (p->drop_rate > 0.f ? 1.f - p->drop_rate : 1.f),
+                              wn_debug_get(1) != 1, loss_out + 2, s);
     if (rc) return rc;
+    if (p->phase_on) (void)hipEventRecord(p->phase_ev[2], s);
+    return WN_OK;
   }
-  // the step's other two scalars are complete here too: the L2 regulariser's loss term (src/model.py:331-334) and the
-  // range flag of the forward pass
-  if (p->c.l2_reg_factor > 0.f) {
-    float* norms = ws + L.loss_rows;   // free by now
-    rc = wn_launch_sumsq(params, p->d_kdesc, (int)p->kdesc.size(), norms, s);
-    if (rc) return rc;
-    rc = wn_launch_sum(norms, (int64_t)p->kdesc.size(), p->c.l2_reg_factor / (float)n_replicas, loss_out + 1, ws + L.sum_scratch, s);
-    if (rc) return rc;
-  } else {
-    rc = wn_launch_fill(loss_out + 1, 0.f, 1, s);
-    if (rc) return rc;
-  }
-  // (with dropout the split kernels read H * mask / (1 - rate) while only H is published: compare against limit * (1 - rate))
-  rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT * (p->drop_rate > 0.f ? 1.f - p->drop_rate : 1.f),
-                            wn_debug_get(1) != 1, loss_out + 2, s);
-  if (rc) return rc;
-  if (p->phase_on) (void)hipEventRecord(p->phase_ev[2], s);
-  }
-  if (!(phases & 2)) return WN_OK;
-  const float* fragbase = ws + L.frag;
-  float* slab = ws + L.slab;
 
-  const bool defer = deferred_wgrad(p);
-  const float* mlast = nullptr;
-  if (p->c.cond_inputs > 0) {
-    mlast = p->mapping.empty() ? cond : ws + L.M.back();
-    rc = wn_launch_fill(ws + L.g_m0, 0.f, (int64_t)B * p->Cc, s);
-    if (rc) return rc;
-  }
-  auto cond_block_bwd = [&](const BlockInfo& bi) -> int {
-    // conv_cond on the time-invariant mapped condition: dW_c = m^T dcb, db_c = sum_b dcb,
-    // g_m += dcb W_c^T
+  // conv_cond of ONE block on the time-invariant mapped condition: dW_c = m^T dcb, db_c = sum_b dcb, g_m += dcb W_c^T
+  int cond_block_bwd(const BlockInfo& bi) {
     const ConvInfo& c = bi.conv_cond;
     int r = wgrad(mlast, p->Cc, p->Cc, 0, ws + L.dcb, 2 * p->D, 2 * p->D, 1, B, grads + p->tensors[c.kernel_t].off,
                   grads + p->tensors[c.bias_t].off, nullptr, slab, s);
     if (r) return r;
     return Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.dcb, 2 * p->D, 2 * p->D, 0, fragbase + c.fragB)
         .addc(ws + L.g_m0, p->Cc).run(ws + L.g_m0, p->Cc, s);
-  };
+  }
 
-  // conditioning of all blocks as one layer: the per-utterance sums of d u come out of the weight-gradient
-  // slab afterwards instead of 2 column-sum launches + 3 tiny products per block (knob 14 = 1: per block)
-  const bool cond_batched = defer && p->frag_condB >= 0 && wn_debug_get(14) != 1;
-  if (defer) {
-    // ================= data gradients now, every weight gradient in one batched launch =================
-    rc = ensure_jobs(p, L, B, T);
-    if (rc) return rc;
-    // (the loss stage wrote d loss / d logits straight into GF.back(), the last final layer's g)
-    const bool fold = fold_ok(p);                  // (the forward pass of this call made the same decision)
+  // ---- head, last conv first: d loss / d logits (written by the loss stage into GF.back()) down to the skip sum ----
+  int head_backward() {
+    int rc;
     float* head_out = p->c.use_skip ? ws + L.g_skipsum : ws + L.GH[p->N];
     for (int i = (int)p->finals.size() - 1; i >= (fold ? 1 : 0); --i) {
       const ConvInfo& c = p->finals[i];
       float* dst = (i == 0) ? head_out : ws + L.GF[i - 1];
-      // 128 / 256 input channels: the streamed kernel's second form in its backward-data instantiation (knob 31 = 1: rows GEMM)
-      if (c.frag16B >= 0 && wn_debug_get(1) != 1 && wn_debug_get(31) != 1 && wn_gemm_planes16s_supported(c.cin, c.cout, 1, c.cout, c.cin) &&
+      // 128 / 256 input channels: the streamed kernel's second form in its backward-data instantiation
+      if (c.frag16B >= 0 && wn_debug_get(1) != 1 && wn_gemm_planes16s_supported(c.cin, c.cout, 1, c.cout, c.cin) &&
           (int64_t)rows * c.cout * 4 < ((int64_t)1 << 32)) {
         WnGemmPlanesArgs ga;
         memset(&ga, 0, sizeof(ga));
@@ -394,34 +347,23 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       rc = gm.run(dst, c.cin, s);
       if (rc) return rc;
     }
+    return WN_OK;
+  }
+
+  // ---- residual blocks, last to first: data gradients only, every g_u / g_x is kept for the deferred weight gradients ----
+  int chain_backward() {
+    int rc;
     // folded skip path: the gradient of the skip sum is never formed; the blocks contract dL/da = GF[0] with V(b)
     const float* g_skip = (p->c.use_skip && !fold) ? ws + L.g_skipsum : nullptr;
     if (p->c.use_skip) {
       rc = wn_launch_fill(ws + L.GH[p->N], 0.f, rows * p->R, s);   // nothing flows into the last block output
       if (rc) return rc;
     }
-    // W_s g_skip of every block in ONE contraction: each block then reads its D-column slice (33 MB at
-    // configs[1]) instead of re-reading g_skip (131 MB).  Measured SLOWER on configs[1] (round 1: 12.6 vs 12.0 ms
-    // per step; round 2, also with a block-major [N][rows][D] result so that the slices are contiguous: 8.59 vs
-    // 7.68 ms -- the K = 256, N = 1920 product costs ~1.5 ms, far more than the re-reads it saves), so it is
-    // opt-in (knob 4 = 1).
-    bool have_gzs = false;
-    if (L.GZS > 0 && p->frag16_gzs >= 0 && wn_debug_get(1) != 1 && wn_debug_get(4) == 1) {
-      Gemm gz(B, T, p->N * p->D, p->N * p->D / 32);
-      gz.seg(g_skip, p->S, p->S, 0, nullptr).w16(fragbase + p->frag16_gzs).absmax(am_gskip, nullptr, nullptr);
-      gz.a.y = ws + L.GZS; gz.a.ldy = p->N * p->D; gz.a.vec_out = 1;
-      if (wn_gemm_rows16_ok(gz.a)) {
-        rc = gz.run(ws + L.GZS, p->N * p->D, s);
-        if (rc) return rc;
-        have_gzs = true;
-      }
-    }
     // Two products per launch (wn_bwd_pair.hip): g_x(b+1) and, from it in registers, g_u(b).  The chain is then
-    //   g_u(N-1) | { g_x(b+1), g_u(b) } for b = N-2 .. 0 | g_x(0)   = N + 1 launches instead of 2 N.   knob 22 = 1: two launches per block
-    const bool pairk = fold && p->N >= 2 && p->drop_rate == 0.f && p->c.use_residual && (p->c.cond_inputs == 0 || cond_batched) && !have_gzs &&
+    //   g_u(N-1) | { g_x(b+1), g_u(b) } for b = N-2 .. 0 | g_x(0)   = N + 1 launches instead of 2 N.
+    const bool pairk = fold && p->N >= 2 && p->drop_rate == 0.f && p->c.use_residual && (p->c.cond_inputs == 0 || cond_batched) &&
                        (wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) || wn_bwd_s128_supported(p->R, p->D, p->KS, p->fold_F0)) &&
-                       p->Dp == p->D && wn_debug_get(22) != 1 &&
-                       wn_debug_get(15) != 1 &&
+                       p->Dp == p->D &&
                        // (the streamed R = 128 pair kernel indexes with 32-bit byte offsets: the two-launch chain takes over beyond)
                        (p->R != 128 || (int64_t)rows * 2 * p->D * 4 < ((int64_t)1 << 32));
     for (int b = p->N - 1; b >= 0; --b) {
@@ -473,7 +415,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       //  still passed as a gradient -- unless S == 0, where g_o is assembled from g_skip alone -- so that
       //  the last block runs the same split-precision kernels as the others instead of the fp32 fallback
       //  for the one-segment product)
-      bg.g_xout = (p->c.use_skip && b == p->N - 1 && (p->S == 0 || wn_debug_get(15) == 1)) ? nullptr : ws + L.GH[b + 1];
+      bg.g_xout = (p->c.use_skip && b == p->N - 1 && p->S == 0) ? nullptr : ws + L.GH[b + 1];
       bg.g_skip = g_skip;
       bg.g_o_tmp = p->S == 0 ? ws + L.GO[b] : nullptr;
       bg.g_u = ws + L.GU[b];
@@ -483,7 +425,6 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       bg.am_gxout = bg.g_xout ? am_GH(b + 1) : nullptr;
       bg.am_gskip = g_skip ? am_gskip : nullptr;
       bg.am_gu = am_GU(b); bg.am_gx = am_GH(b);
-      if (have_gzs) { bg.gzs = ws + L.GZS + (int64_t)b * p->D; bg.ld_gzs = p->N * p->D; }
       if (fold) { bg.g_fold = ws + L.GF[0]; bg.fold_F0 = p->fold_F0; bg.am_gfold = am_GF(0); }
       rc = block_backward(k, f, bg, s);
       if (rc) return rc;
@@ -496,10 +437,91 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         if (rc) return rc;
       }
     }
+    return WN_OK;
+  }
+
+  // folded skip path: M = Z^T dL/da -> dW_s, db_s of every block and dW_f0, db_f0 (three small weight-space products)
+  int fold_weight_gradients() {
+    int rc = WN_OK;
+    // M = Z^T dL/da (N*D x F0) and colsum(dL/da) into their own slab, reduced, then the three small products
+    const int F0 = p->fold_F0;
+    const int64_t pm = (int64_t)p->N * p->D * F0 + F0;
+    if (p->jobs_mtr != 0)
+      rc = wn_launch_wgrad_tr(p->jobs_mtr, p->d_pairs + p->pair_first[0], p->pair_count[0], ws, ws + L.mslab, pm, B, T,
+                              L.bsplits, s);
+    else if (!p->jobs_mfused)
+    rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.GF[0], F0, rows, p->N * p->D, F0, p->D, B * L.bsplits, ws + L.mslab, pm,
+                              0, (int64_t)p->D * F0, (int64_t)p->N * p->D * F0, 0, 1, am_GF(0), s);
+    if (rc) return rc;
+    rc = wn_launch_reduce_table(ws + L.mslab, B * L.bsplits, pm, ws + L.mtot, p->d_cov_fold, 1, s, &p->h_cov_fold);
+    if (rc) return rc;
+    const BlockInfo& b0 = p->blocks[0];
+    const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
+    const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.bias_t].off - p->tensors[b0.conv_skip.bias_t].off : 0;
+    // Y = [M; colsum] W_f0^T -> dW_s of every block and db_s;  dW_f0 = [W_s(all); sum b_s]^T [M; colsum];  db_f0 = colsum
+    const ConvInfo& c0 = p->finals[0];
+    const int nd1 = p->N * p->D + 1;
+    const float* wf0 = params + p->tensors[c0.kernel_t].off;          // (1, S, F0): W_f0[s][n]
+    rc = wn_launch_sgemm_small(ws + L.mtot, F0, 1, wf0, 1, F0, ws + L.ytmp, p->S, nd1, p->S, F0, s);          // B[k = n][j = s]
+    if (rc) return rc;
+    // (a long-K product with a small output: the rows-contraction kernel splits K over workgroups)
+    // split K in chunks of 128 on the small-product kernel, partial results in the (idle) slab, summed in chunk order
+    // (wn_wgrad_kernel when the slab is too small for them)
+    const int nzk = (nd1 + 127) / 128;
+    if ((int64_t)nzk * p->S * F0 <= L.slab_floats) {
+      rc = wn_launch_sgemm_small_batched(ws + L.wsall, 1, p->S, (int64_t)128 * p->S, ws + L.mtot, F0, 1, (int64_t)128 * F0, slab, F0,
+                                         (int64_t)p->S * F0, p->S, F0, nd1, nzk, nullptr, 0, s, 128);
+      if (rc) return rc;
+      WnVecSumArgs v;
+      v.base = slab; v.off0 = 0; v.stride = (int64_t)p->S * F0; v.count = nzk; v.len = p->S * F0;
+      v.out = grads + p->tensors[c0.kernel_t].off;
+      rc = wn_launch_vecsum(v, s);
+    } else
+    rc = wgrad(ws + L.wsall, p->S, p->S, 0, ws + L.mtot, F0, F0, 1, nd1, grads + p->tensors[c0.kernel_t].off, nullptr, nullptr,
+               slab, s);
+    if (rc) return rc;
+    rc = wn_launch_skip_scatter(ws + L.ytmp, ws + L.mtot + (int64_t)p->N * p->D * F0, p->tensors[b0.conv_skip.kernel_t].off, wst,
+                                p->tensors[b0.conv_skip.bias_t].off, bst, p->tensors[c0.bias_t].off, p->N, p->D, p->S, F0, grads, s);
+    if (rc) return rc;
+    return WN_OK;
+  }
+
+  // global conditioning of all blocks as one layer: per-utterance sums of d u out of the weight-gradient slab, g_m, dW_c, db_c
+  int cond_weight_gradients() {
+    int rc;
+    const int D2 = 2 * p->D;
+    const BlockInfo& b0 = p->blocks[0];
+    const int64_t dst = p->N > 1 ? p->tensors[p->blocks[1].dil.back().bias_t].off - p->tensors[b0.dil.back().bias_t].off : 0;
+    const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.kernel_t].off - p->tensors[b0.conv_cond.kernel_t].off : 0;
+    const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.bias_t].off - p->tensors[b0.conv_cond.bias_t].off : 0;
+    rc = wn_launch_cond_gather(ws + L.bslab, p->nparams, L.bsplits, p->tensors[b0.dil.back().bias_t].off, dst, B, p->N, D2,
+                               ws + L.cbt, s);
+    if (rc) return rc;
+    if (cond_small(p) && (int64_t)p->N * B * p->Cc <= L.slab_floats) {
+      // g_m = sum_z dcb_z W_c(z)^T: one product per block into the (idle) slab, then their sum
+      rc = wn_launch_sgemm_small_batched(ws + L.cbt, p->N * D2, 1, D2, params + p->tensors[b0.conv_cond.kernel_t].off, 1, D2, wst,
+                                         slab, p->Cc, (int64_t)B * p->Cc, B, p->Cc, D2, p->N, nullptr, 0, s);
+      if (rc) return rc;
+      WnVecSumArgs v;
+      v.base = slab; v.off0 = 0; v.stride = (int64_t)B * p->Cc; v.count = p->N; v.len = B * p->Cc; v.out = ws + L.g_m0;
+      rc = wn_launch_vecsum(v, s);
+    } else
+    rc = Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.cbt, p->N * D2, p->N * D2, 0, fragbase + p->frag_condB).run(ws + L.g_m0, p->Cc, s);
+    if (rc) return rc;
+    rc = wn_launch_cond_wgrad(mlast, ws + L.cbt, B, p->Cc, p->N, D2, grads, p->tensors[b0.conv_cond.kernel_t].off, wst,
+                              p->tensors[b0.conv_cond.bias_t].off, bst, s);
+    if (rc) return rc;
+    return WN_OK;
+  }
+
+  // ---- every weight gradient of the step: per-block kernels on the caller's stream, the low-occupancy leftovers (input
+  //      conv, head) beside them on a side stream, then the slab reductions into the flat gradient ----
+  int weight_gradients() {
+    int rc;
     if (p->phase_on) (void)hipEventRecord(p->phase_ev[3], s);      // backward-data chain done
     // the generic jobs left over (input conv, head) are few single-wave jobs: they run beside the
     // per-block and skip kernels on a side stream (disjoint slab regions), joined before the reduce.
-    // knob 9 = 1 keeps everything on the caller's stream.
+    // knob 9 = 1 keeps everything on the caller's stream (A/B of the overlap).
     const bool fork = (p->jobs_layerk || p->jobs_pairk) && wn_debug_get(9) != 1;
     if (fork && !p->side) {
       WN_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
@@ -541,9 +563,9 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       if (p->jobs_headpairs)
         for (int kd = 1; kd <= 5; ++kd)
           if (p->hpair_count[kd] > 0) {
-            // staged kinds 1 (128 x 256), 3 (256 x 128), 5 (256 x 256 halves) have transposed-read forms (3, 4, 5); knob 16 = 1: staged
+            // staged kinds 1 (128 x 256), 3 (256 x 128), 5 (256 x 256 halves) have transposed-read forms (3, 4, 5)
             const int trk = kd == 1 ? 3 : (kd == 3 ? 4 : (kd == 5 ? 5 : (kd == 2 ? 2 : 0)));
-            if (trk != 0 && p->jobs_pair_mode == 2)        // (with 64-channel blocks the staged head jobs are faster beside the side stream's neighbours)
+            if (trk != 0 && p->jobs_pairk)                 // (with 64-channel blocks the staged head jobs are faster beside the side stream's neighbours)
               rc = wn_launch_wgrad_tr(trk, p->d_pairs + p->hpair_first[kd], p->hpair_count[kd], ws, ws + L.hslab - L.head_base,
                                       L.head_span, B, T, L.hsplits, fork ? p->side : s);
             else
@@ -555,13 +577,10 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
     for (int kd = 1; kd <= 2; ++kd)
       if (p->jobs_pairk && p->pair_count[kd] > 0) {
-        if (p->jobs_pair_mode == 2)                     // transposed-read kernels: both taps of dW_d in one job; dW_r (+ M)
-          rc = wn_launch_wgrad_tr(kd == 2 && p->jobs_mfused ? 6 : kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws,
-                                  ws + L.bslab, p->nparams, B, T, L.bsplits, s, ws + L.mslab,
-                                  (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0);
-        else
-          rc = wn_launch_wgrad_pairs(kd == 1 && p->jobs_pair_mode == 1 ? 6 : kd, p->d_pairs + p->pair_first[kd],
-                                     p->pair_count[kd], ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
+        // transposed-read kernels: both taps of dW_d in one job; dW_r (+ M)
+        rc = wn_launch_wgrad_tr(kd == 2 && p->jobs_mfused ? 6 : kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws,
+                                ws + L.bslab, p->nparams, B, T, L.bsplits, s, ws + L.mslab,
+                                (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0);
         if (rc) return rc;
       }
     if (p->jobs_layerk) {
@@ -571,45 +590,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
       if (rc) return rc;
     }
     if (fold) {
-      // M = Z^T dL/da (N*D x F0) and colsum(dL/da) into their own slab, reduced, then the three small products
-      const int F0 = p->fold_F0;
-      const int64_t pm = (int64_t)p->N * p->D * F0 + F0;
-      if (p->jobs_mtr != 0)
-        rc = wn_launch_wgrad_tr(p->jobs_mtr, p->d_pairs + p->pair_first[0], p->pair_count[0], ws, ws + L.mslab, pm, B, T,
-                                L.bsplits, s);
-      else if (!p->jobs_mfused)
-      rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.GF[0], F0, rows, p->N * p->D, F0, p->D, B * L.bsplits, ws + L.mslab, pm,
-                                0, (int64_t)p->D * F0, (int64_t)p->N * p->D * F0, 0, 1, am_GF(0), s);
-      if (rc) return rc;
-      rc = wn_launch_reduce_table(ws + L.mslab, B * L.bsplits, pm, ws + L.mtot, p->d_cov_fold, 1, s, &p->h_cov_fold);
-      if (rc) return rc;
-      const BlockInfo& b0 = p->blocks[0];
-      const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
-      const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.bias_t].off - p->tensors[b0.conv_skip.bias_t].off : 0;
-      // Y = [M; colsum] W_f0^T -> dW_s of every block and db_s;  dW_f0 = [W_s(all); sum b_s]^T [M; colsum];  db_f0 = colsum
-      const ConvInfo& c0 = p->finals[0];
-      const int nd1 = p->N * p->D + 1;
-      const float* wf0 = params + p->tensors[c0.kernel_t].off;          // (1, S, F0): W_f0[s][n]
-      rc = wn_launch_sgemm_small(ws + L.mtot, F0, 1, wf0, 1, F0, ws + L.ytmp, p->S, nd1, p->S, F0, s);          // B[k = n][j = s]
-      if (rc) return rc;
-      // (a long-K product with a small output: the rows-contraction kernel splits K over workgroups)
-      // knob 37 = 1: wn_wgrad_kernel; default: split K in chunks of 128 on the small-product kernel, partial results in the
-      // (idle) slab, summed in chunk order
-      const int nzk = (nd1 + 127) / 128;
-      if (wn_debug_get(37) != 1 && (int64_t)nzk * p->S * F0 <= L.slab_floats) {
-        rc = wn_launch_sgemm_small_batched(ws + L.wsall, 1, p->S, (int64_t)128 * p->S, ws + L.mtot, F0, 1, (int64_t)128 * F0, slab, F0,
-                                           (int64_t)p->S * F0, p->S, F0, nd1, nzk, nullptr, 0, s, 128);
-        if (rc) return rc;
-        WnVecSumArgs v;
-        v.base = slab; v.off0 = 0; v.stride = (int64_t)p->S * F0; v.count = nzk; v.len = p->S * F0;
-        v.out = grads + p->tensors[c0.kernel_t].off;
-        rc = wn_launch_vecsum(v, s);
-      } else
-      rc = wgrad(ws + L.wsall, p->S, p->S, 0, ws + L.mtot, F0, F0, 1, nd1, grads + p->tensors[c0.kernel_t].off, nullptr, nullptr,
-                 slab, s);
-      if (rc) return rc;
-      rc = wn_launch_skip_scatter(ws + L.ytmp, ws + L.mtot + (int64_t)p->N * p->D * F0, p->tensors[b0.conv_skip.kernel_t].off, wst,
-                                  p->tensors[b0.conv_skip.bias_t].off, bst, p->tensors[c0.bias_t].off, p->N, p->D, p->S, F0, grads, s);
+      rc = fold_weight_gradients();
       if (rc) return rc;
     } else if (p->jobs_skipk) {
       const BlockInfo& b0 = p->blocks[0];
@@ -622,27 +603,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
     }
     if (fork) { WN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0)); side_join.armed = false; }
     if (cond_batched) {
-      const int D2 = 2 * p->D;
-      const BlockInfo& b0 = p->blocks[0];
-      const int64_t dst = p->N > 1 ? p->tensors[p->blocks[1].dil.back().bias_t].off - p->tensors[b0.dil.back().bias_t].off : 0;
-      const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.kernel_t].off - p->tensors[b0.conv_cond.kernel_t].off : 0;
-      const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_cond.bias_t].off - p->tensors[b0.conv_cond.bias_t].off : 0;
-      rc = wn_launch_cond_gather(ws + L.bslab, p->nparams, L.bsplits, p->tensors[b0.dil.back().bias_t].off, dst, B, p->N, D2,
-                                 ws + L.cbt, s);
-      if (rc) return rc;
-      if (cond_small(p) && (int64_t)p->N * B * p->Cc <= L.slab_floats) {
-        // g_m = sum_z dcb_z W_c(z)^T: one product per block into the (idle) slab, then their sum
-        rc = wn_launch_sgemm_small_batched(ws + L.cbt, p->N * D2, 1, D2, params + p->tensors[b0.conv_cond.kernel_t].off, 1, D2, wst,
-                                           slab, p->Cc, (int64_t)B * p->Cc, B, p->Cc, D2, p->N, nullptr, 0, s);
-        if (rc) return rc;
-        WnVecSumArgs v;
-        v.base = slab; v.off0 = 0; v.stride = (int64_t)B * p->Cc; v.count = p->N; v.len = B * p->Cc; v.out = ws + L.g_m0;
-        rc = wn_launch_vecsum(v, s);
-      } else
-      rc = Gemm(1, B, p->Cc, ceil32(p->Cc)).seg(ws + L.cbt, p->N * D2, p->N * D2, 0, fragbase + p->frag_condB).run(ws + L.g_m0, p->Cc, s);
-      if (rc) return rc;
-      rc = wn_launch_cond_wgrad(mlast, ws + L.cbt, B, p->Cc, p->N, D2, grads, p->tensors[b0.conv_cond.kernel_t].off, wst,
-                                p->tensors[b0.conv_cond.bias_t].off, bst, s);
+      rc = cond_weight_gradients();
       if (rc) return rc;
     }
     // coverage entries 0, 1 are the input conv's kernel and bias: from their compact slab when the dedicated kernel ran
@@ -666,116 +627,116 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
         if (rc) return rc;
       }
     }
-  } else {
-  // ================= per-call weight gradients (blocks with depth > 1) =================
-  // ---- head backward ----
-  const float* g = ws + L.g_a;          // d loss / d logits
-  float* gnext = ws + L.g_b;
-  for (int i = (int)p->finals.size() - 1; i >= 0; --i) {
-    const ConvInfo& c = p->finals[i];
-    const float* xin = (i == 0) ? (p->c.use_skip ? ws + L.skipsum : ws + L.H[p->N]) : ws + L.HA[i - 1];
-    rc = wgrad(xin, c.cin, c.cin, 0, g, c.cout, c.cout, B, T, grads + p->tensors[c.kernel_t].off,
-               grads + p->tensors[c.bias_t].off, nullptr, slab, s);
-    if (rc) return rc;
-    Gemm gm(B, T, c.cin, ceil32(c.cin));
-    gm.seg(g, c.cout, c.cout, 0, fragbase + c.fragB);
-    float* dst = (i == 0) ? ws + L.g_skipsum : gnext;
-    if (i > 0) gm.dact(ws + L.HA[i - 1], c.cin, p->c.activation);
-    rc = gm.run(dst, c.cin, s);
-    if (rc) return rc;
-    if (i > 0) { const float* t = g; g = dst; gnext = const_cast<float*>(t); }
+    return WN_OK;
   }
-  // ---- blocks, last to first ----
-  const float* g_skip = p->c.use_skip ? ws + L.g_skipsum : nullptr;
-  const float* g_xout = p->c.use_skip ? nullptr : ws + L.g_skipsum;   // head fed by the last block output
-  float* ghbuf[2] = {ws + L.g_h0, ws + L.g_h1};
-  for (int b = p->N - 1; b >= 0; --b) {
-    BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
-    const BlockInfo& bi = p->blocks[b];
-    BlockBufs f;
-    memset(&f, 0, sizeof(f));
-    f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
-    for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
-    f.AG = ws + L.AG[b];
-    f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;
-    BlockGrads bg;
-    memset(&bg, 0, sizeof(bg));
-    if (p->drop_rate > 0.f) {
-      bg.drop_rate = p->drop_rate; bg.drop_key = wn_dropout_key(p->drop_seed, b, p->drop_step); bg.g_xd = ws + L.gxd;
-    }
-    bg.g_xout = g_xout; bg.g_skip = g_skip; bg.g_o_tmp = ws + L.g_o; bg.g_u = ws + L.U; bg.g_p = ws + L.g_p;
-    bg.g_x = ghbuf[b & 1];
-    for (int i = 0; i < p->LPB; ++i) {
-      bg.dWd[i] = grads + p->tensors[bi.dil[i].kernel_t].off;
-      bg.dbd[i] = grads + p->tensors[bi.dil[i].bias_t].off;
-    }
-    bg.dWr = grads + p->tensors[bi.conv1.kernel_t].off; bg.dbr = grads + p->tensors[bi.conv1.bias_t].off;
-    if (bi.has_skip) { bg.dWs = grads + p->tensors[bi.conv_skip.kernel_t].off; bg.dbs = grads + p->tensors[bi.conv_skip.bias_t].off; }
-    bg.dcb = bi.has_cond ? ws + L.dcb : nullptr;
-    bg.slab = slab;
-    rc = block_backward(k, f, bg, s);
-    if (rc) return rc;
-    if (bi.has_cond) {
-      rc = cond_block_bwd(bi);
-      if (rc) return rc;
-    }
-    g_xout = bg.g_x;
-  }
-  // ---- input causal conv: only weight gradients ----
-  for (int t = 0; t < p->KS; ++t) {
-    rc = wgrad(inputs, 1, 1, (p->KS - 1 - t), g_xout, p->R, p->R, B, T,
-               grads + p->tensors[p->causal.kernel_t].off + (int64_t)t * p->R,
-               (t == p->KS - 1) ? grads + p->tensors[p->causal.bias_t].off : nullptr, nullptr, slab, s);
-    if (rc) return rc;
-  }
-  }
-  // ---- mapping Dense stack backward ----
-  if (p->c.cond_inputs > 0) {
-    const float* gm_cur = ws + L.g_m0;      // gradient w.r.t. post-activation output of the last Dense
-    float* gm_other = ws + L.g_m1;
-    for (int j = (int)p->mapping.size() - 1; j >= 0; --j) {
-      const ConvInfo& c = p->mapping[j];
-      const float* yin = (j == 0) ? cond : ws + L.M[j - 1];
-      // pre-activation gradient g_pre = g * act'(M[j])  (tiny: B x width)
-      rc = wn_launch_dact_mul(gm_cur, ws + L.M[j], gm_other, (int64_t)B * c.cout, p->c.mapping_activation, s);
-      if (rc) return rc;
-      if (cond_small(p)) {
-        // dW = yin^T g_pre (cin x cout, contraction over the B utterances), db = column sums of g_pre
-        rc = wn_launch_sgemm_small_batched(yin, 1, c.cin, 0, gm_other, c.cout, 1, 0, grads + p->tensors[c.kernel_t].off, c.cout, 0,
-                                           c.cin, c.cout, B, 1, nullptr, 0, s);
+
+  int mapping_backward() {
+    int rc;
+    // ---- mapping Dense stack backward ----
+    if (p->c.cond_inputs > 0) {
+      const float* gm_cur = ws + L.g_m0;      // gradient w.r.t. post-activation output of the last Dense
+      float* gm_other = ws + L.g_m1;
+      for (int j = (int)p->mapping.size() - 1; j >= 0; --j) {
+        const ConvInfo& c = p->mapping[j];
+        const float* yin = (j == 0) ? cond : ws + L.M[j - 1];
+        // pre-activation gradient g_pre = g * act'(M[j])  (tiny: B x width)
+        rc = wn_launch_dact_mul(gm_cur, ws + L.M[j], gm_other, (int64_t)B * c.cout, p->c.mapping_activation, s);
         if (rc) return rc;
-        WnVecSumArgs v;
-        v.base = gm_other; v.off0 = 0; v.stride = c.cout; v.count = B; v.len = c.cout; v.out = grads + p->tensors[c.bias_t].off;
-        rc = wn_launch_vecsum(v, s);
+        if (cond_small(p)) {
+          // dW = yin^T g_pre (cin x cout, contraction over the B utterances), db = column sums of g_pre
+          rc = wn_launch_sgemm_small_batched(yin, 1, c.cin, 0, gm_other, c.cout, 1, 0, grads + p->tensors[c.kernel_t].off, c.cout, 0,
+                                             c.cin, c.cout, B, 1, nullptr, 0, s);
+          if (rc) return rc;
+          WnVecSumArgs v;
+          v.base = gm_other; v.off0 = 0; v.stride = c.cout; v.count = B; v.len = c.cout; v.out = grads + p->tensors[c.bias_t].off;
+          rc = wn_launch_vecsum(v, s);
+          if (rc) return rc;
+          if (j > 0) {          // g_in = g_pre W^T
+            float* dst = const_cast<float*>(gm_cur);
+            rc = wn_launch_sgemm_small_batched(gm_other, c.cout, 1, 0, params + p->tensors[c.kernel_t].off, 1, c.cout, 0, dst, c.cin, 0,
+                                               B, c.cin, c.cout, 1, nullptr, 0, s);
+            if (rc) return rc;
+          }
+          continue;
+        }
+        rc = wgrad(yin, c.cin, c.cin, 0, gm_other, c.cout, c.cout, 1, B, grads + p->tensors[c.kernel_t].off,
+                   grads + p->tensors[c.bias_t].off, nullptr, slab, s);
         if (rc) return rc;
-        if (j > 0) {          // g_in = g_pre W^T
+        if (j > 0) {
           float* dst = const_cast<float*>(gm_cur);
-          rc = wn_launch_sgemm_small_batched(gm_other, c.cout, 1, 0, params + p->tensors[c.kernel_t].off, 1, c.cout, 0, dst, c.cin, 0,
-                                             B, c.cin, c.cout, 1, nullptr, 0, s);
+          rc = Gemm(1, B, c.cin, ceil32(c.cin)).seg(gm_other, c.cout, c.cout, 0, fragbase + c.fragB).run(dst, c.cin, s);
           if (rc) return rc;
         }
-        continue;
-      }
-      rc = wgrad(yin, c.cin, c.cin, 0, gm_other, c.cout, c.cout, 1, B, grads + p->tensors[c.kernel_t].off,
-                 grads + p->tensors[c.bias_t].off, nullptr, slab, s);
-      if (rc) return rc;
-      if (j > 0) {
-        float* dst = const_cast<float*>(gm_cur);
-        rc = Gemm(1, B, c.cin, ceil32(c.cin)).seg(gm_other, c.cout, c.cout, 0, fragbase + c.fragB).run(dst, c.cin, s);
-        if (rc) return rc;
       }
     }
+    return WN_OK;
   }
-  // ---- L2 regulariser, src/model.py:331-334: its gradient (the loss term is formed with the loss, above) ----
-  if (p->c.l2_reg_factor > 0.f) {
-    rc = wn_launch_axpy_table(grads, params, p->d_kdesc, (int)p->kdesc.size(), 2.0f * p->c.l2_reg_factor / (float)n_replicas, s);
+
+  int backward() {
+    int rc;
+    fragbase = ws + L.frag;
+    slab = ws + L.slab;
+    if (p->c.cond_inputs > 0) {
+      mlast = p->mapping.empty() ? cond : ws + L.M.back();
+      rc = wn_launch_fill(ws + L.g_m0, 0.f, (int64_t)B * p->Cc, s);
+      if (rc) return rc;
+    }
+    // conditioning of all blocks as one layer: the per-utterance sums of d u come out of the weight-gradient
+    // slab afterwards instead of 2 column-sum launches + 3 tiny products per block
+    cond_batched = p->frag_condB >= 0;
+    fold = fold_ok(p);                             // (the forward pass of this call made the same decision)
+    rc = ensure_jobs(p, L, B, T);
     if (rc) return rc;
+    if ((rc = head_backward())) return rc;
+    if ((rc = chain_backward())) return rc;
+    if ((rc = weight_gradients())) return rc;
+    if ((rc = mapping_backward())) return rc;
+    // ---- L2 regulariser, src/model.py:331-334: its gradient (the loss term is formed with the loss, above) ----
+    if (p->c.l2_reg_factor > 0.f) {
+      rc = wn_launch_axpy_table(grads, params, p->d_kdesc, (int)p->kdesc.size(), 2.0f * p->c.l2_reg_factor / (float)n_replicas, s);
+      if (rc) return rc;
+    }
+    if (p->phase_on) {
+      (void)hipEventRecord(p->phase_ev[4], s);
+    }
+
+    return WN_OK;
   }
-  if (p->phase_on) {
-    if (!defer) (void)hipEventRecord(p->phase_ev[3], s);             // per-call weight gradients: no separate phase
-    (void)hipEventRecord(p->phase_ev[4], s);
-  }
+};
+
+}  // namespace
+
+extern "C" int wn_plan_set_train_phases(wn_plan* p, int32_t phases) {
+  if (!p || phases < 1 || phases > 3) { wn_set_error("set_train_phases: 1 (forward + loss), 2 (backward), 3 (both)"); return WN_E_INVALID; }
+  p->train_phases = phases;
   return WN_OK;
+}
+
+extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_full, const float* cond,
+                                int32_t B, int32_t T, int32_t global_batch, int32_t n_replicas, float* grads,
+                                float* loss_out, float* pred_out, float* workspace, int64_t ws_floats,
+                                void* stream) {
+  if (!p || !params || !x_full || !workspace || !loss_out || !grads || B < 1 || T < 1) { wn_set_error("train_fwd_bwd: bad arguments"); return WN_E_INVALID; }
+  TrainCall c;
+  c.p = p; c.params = params; c.x_full = x_full; c.cond = cond; c.B = B; c.T = T;
+  c.global_batch = global_batch > 0 ? global_batch : B;
+  c.n_replicas = n_replicas > 0 ? n_replicas : 1;
+  c.grads = grads; c.loss_out = loss_out; c.pred_out = pred_out; c.ws = workspace; c.s = (hipStream_t)stream;
+  c.L = make_layout(p, B, T, true);
+  if (ws_floats < c.L.total) { wn_set_error("train_fwd_bwd: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)c.L.total); return WN_E_INVALID; }
+  c.rows = (int64_t)B * T;
+  c.inputs = workspace + c.L.probs;
+  c.am = workspace + c.L.absmax;
+  c.nf = (int)p->finals.size();
+  c.am_gskip = c.am + c.nf;
+  // A caller may run the step as two calls (wn_plan_set_train_phases 1, then 2) and queue work of its own in between --
+  // the Python mirror reads the loss and the metrics back from there, 4 ms before the step ends.  Everything the second
+  // half needs lives in the workspace.
+  const int phases = p->train_phases;
+  int rc = WN_OK;
+  if (phases & 1) rc = c.forward_and_loss();
+  if (!rc && (phases & 2)) rc = c.backward();
+  return rc;
 }
 
 extern "C" int wn_adam_step_guarded(wn_plan* p, float* params, const float* grads, float* m, float* v, int64_t step,

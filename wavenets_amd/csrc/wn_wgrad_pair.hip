@@ -19,10 +19,8 @@
 
 typedef _Float16 wp_h8 __attribute__((ext_vector_type(8)));
 
-// DUAL: the X operand is BOTH taps of a kernel-size-2 convolution, channels [0, KC/2) = x[t - shift], [KC/2, KC) = x[t]
-// (same tensor), against ONE read of G: dW of tap 0 and tap 1 are adjacent in the flat layout (tap-major (2, R, N)), so
-// the 32 KT output rows are simply rows of the two stacked matrices.  TK_ = row tiles per wave.
-template <int LDX, int LDG, int KT, int NT, int LDW = 32 * NT, int TK_ = 2, bool DUAL = false>
+// TK_ = row tiles per wave.
+template <int LDX, int LDG, int KT, int NT, int LDW = 32 * NT, int TK_ = 2>
 __global__ __launch_bounds__(64 * (KT / TK_) * (NT / 2)) void wn_wgrad_pair_kernel(const WnWgPair* jobs, float* ws, float* slab,
                                                                                 int64_t P, int B, int T, int spb) {
   constexpr int KC = 32 * KT, NC = 32 * NT, NCH = KC + NC;
@@ -58,8 +56,8 @@ __global__ __launch_bounds__(64 * (KT / TK_) * (NT / 2)) void wn_wgrad_pair_kern
   const bool xunit = tid < 2 * KC, gunit = tid < 2 * NC;
   const int cx = xunit ? tid % KC : 0, hx = xunit ? tid / KC : 0;
   const int cg = gunit ? tid % NC : 0, hg = gunit ? tid / NC : 0;
-  const int xshift = DUAL ? (cx < KC / 2 ? shift : 0) : shift;      // this unit's tap
-  const float* xptr = ws + J.x_off + (int64_t)ub * T * LDX + (DUAL ? cx % (KC / 2) : cx);
+  const int xshift = shift;
+  const float* xptr = ws + J.x_off + (int64_t)ub * T * LDX + cx;
   const float* gptr = ws + J.g_off + (int64_t)ub * T * LDG + cg;
   float bsum = 0.f;
 
@@ -222,8 +220,6 @@ int wn_launch_wgrad_pairs(int kind, const WnWgPair* d_jobs, int njobs, float* ws
     case 4: hipLaunchKernelGGL((wn_wgrad_pair_kernel<256, 256, 8, 8>), grid, dim3(1024), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
     // a 128-column half of a 256 x 256 product: G rows and dW rows keep their pitch of 256
     case 5: hipLaunchKernelGGL((wn_wgrad_pair_kernel<256, 256, 8, 4, 256>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
-    // both taps of a 128 -> 256 kernel-size-2 convolution from one read of G (4 x 2 tiles per wave, 8 waves)
-    case 6: hipLaunchKernelGGL((wn_wgrad_pair_kernel<128, 256, 8, 8, 256, 4, true>), grid, dim3(512), 0, s, d_jobs, ws, slab, P, B, T, splits_per_b); break;
     default: wn_set_error("wgrad_pairs: unknown kind %d", kind); return WN_E_UNSUPPORTED;
   }
   WN_HIP_CHECK(hipGetLastError());
