@@ -1097,9 +1097,20 @@ def test_train_step_metric_sample_drawn_inside_the_step(name):
     _, samp, y = model.loss_and_grads(x, want_sample=True)
     assert samp.shape == (3, 300, 1) and float(samp.abs().max()) <= 1.0
     logs[-1]['_samp'] = samp.clone()
-  assert logs[0]['mean_squared_error'] == logs[1]['mean_squared_error']
-  assert logs[0]['loss'] == logs[1]['loss']
-  assert torch.equal(logs[0]['_samp'], logs[1]['_samp'])
+  if name == 'cat_r64':
+    # 256 classes: the in-step draw and the loss are the epilogue of the head's last conv (the logits are never written), the
+    # comparison run goes through pred + sample_waveform.  Same probabilities up to the last bits of their running sums, same
+    # Philox numbers: a drawn class may differ only where the uniform number falls within rounding of a CDF edge.
+    assert abs(logs[0]['loss'] - logs[1]['loss']) <= 1e-6 * abs(logs[1]['loss'])
+    a_, b_ = logs[0]['_samp'], logs[1]['_samp']
+    diff = (a_ != b_)
+    assert int(diff.sum()) <= max(1, a_.numel() // 200), int(diff.sum())
+    assert float((a_ - b_).abs().max()) <= 2.0 / 256 + 1e-7                     # an adjacent class at most
+    assert abs(logs[0]['mean_squared_error'] - logs[1]['mean_squared_error']) <= 1e-3 * logs[1]['mean_squared_error']
+  else:
+    assert logs[0]['mean_squared_error'] == logs[1]['mean_squared_error']
+    assert logs[0]['loss'] == logs[1]['loss']
+    assert torch.equal(logs[0]['_samp'], logs[1]['_samp'])
 
 
 @pytest.mark.parametrize('bits', [9, 11])

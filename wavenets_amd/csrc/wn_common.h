@@ -147,6 +147,9 @@ __device__ __forceinline__ float wn_wave_absmax_bits(float wmax) {
   return v < 3.0e38f ? v : 3.0e38f;
 }
 
+// Keras clips probabilities to [eps, 1 - eps] before the cross entropy (backend.epsilon())
+#define WN_KERAS_EPS 1e-7f
+
 // forward activations at or beyond this magnitude trip the range guard of the split-precision mode (fp16 max 65504)
 #define WN_RANGE_LIMIT 30000.0f
 

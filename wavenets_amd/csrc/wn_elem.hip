@@ -6,7 +6,6 @@
 #include "wn_kernels.h"
 #include "wn_sample.h"
 
-#define WN_KERAS_EPS 1e-7f
 
 static inline int wn_blocks(int64_t n, int per = 256, int cap = 4096) {
   int64_t b = (n + per - 1) / per;

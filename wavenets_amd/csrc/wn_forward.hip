@@ -77,7 +77,7 @@ int ring_capture(const float* src, int B, int T, int C, int nslots, float* ring,
 }
 
 int forward_core(wn_plan* p, const float* params, const float* x, bool prep, const float* cond, int B,
-                 int T, bool training, float* ws, const WsLayout& L, hipStream_t s, const GenRings* rings) {
+                 int T, bool training, float* ws, const WsLayout& L, hipStream_t s, const GenRings* rings, LossFuse* lf) {
   int rc = ensure_device_tables(p);
   if (rc) return rc;
   const int64_t rows = (int64_t)B * T;
@@ -270,6 +270,21 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     const ConvInfo& c = p->finals[i];
     const bool last = (i + 1 == p->finals.size());
     float* dst = last ? ws + L.logits : ws + L.HA[i];
+    // training pass of a 256-class categorical head: the loss is this conv's epilogue (no logits tensor)
+    if (last && lf && loss_fusable(p, rows) && wn_gemm_planes16s_supported(c.cout, hc, 1, hc, c.cout) &&
+        (int64_t)rows * hc * 4 < ((int64_t)1 << 32)) {
+      WnGemmPlanesArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.z = hin; ga.plane_stride = 0; ga.ld = hc; ga.plane_k = hc; ga.nplanes = 1;
+      ga.w16 = fragbase + c.frag16; ga.bias = params + p->tensors[c.bias_t].off; ga.act = WN_ACT_LINEAR;
+      ga.y = lf->g_logits; ga.ldy = c.cout; ga.N = c.cout; ga.B = B; ga.T = T; ga.absmax_out = lf->absmax_out;
+      ga.cat_loss = 1; ga.target = lf->target; ga.gscale = lf->gscale; ga.loss_rows = lf->loss_rows;
+      ga.sample_out = lf->sample_out; ga.inv_lv = lf->inv_lv; ga.seed = lf->seed; ga.offset = lf->offset;
+      rc = wn_launch_gemm_planes16s(ga, s);
+      if (rc) return rc;
+      lf->done = true;
+      break;
+    }
     // 128 / 256 output columns: the streamed kernel's second form (wn_gemm16s.hip; the operand is one "plane"); same
     // products in the same order as the rows GEMM below
     if (c.frag16 >= 0 && wn_debug_get(1) != 1 && wn_gemm_planes16s_supported(c.cout, hc, 1, hc, c.cout) &&
@@ -302,11 +317,20 @@ int shift_split(const float* x_full, int B, int T, float* inputs, float* y_true,
   return WN_OK;
 }
 
+// the split-precision head of a 256-class categorical model whose last conv the streamed 256-column kernel takes
+bool loss_fusable(const wn_plan* p, int64_t rows) {
+  if (p->c.head != WN_HEAD_CATEGORICAL || p->Cout != 256 || wn_debug_get(1) == 1 || p->finals.empty()) return false;
+  const ConvInfo& c = p->finals.back();
+  return c.frag16 >= 0 && c.cout == 256 && rows > 0;
+}
+
 int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float* ws, const WsLayout& L,
-               float* loss_out, float* absmax_out, hipStream_t s) {
+               float* loss_out, float* absmax_out, hipStream_t s, bool fused_done) {
   const int64_t rows = (int64_t)B * T;
   const float gscale = 1.0f / (float)global_batch;     // compute_average_loss, src/model.py:328-329
   int rc;
+  // (the head's last conv already left the row losses and d loss / d logits: see LossFuse)
+  if (fused_done) return wn_launch_sum(ws + L.loss_rows, rows, gscale, loss_out, ws + L.sum_scratch, s);
   // deferred weight gradients read d loss / d logits from GF.back(): written there directly (no 131 MB copy)
   float* g_logits = want_grad ? ws + L.GF.back() : nullptr;
   if (p->c.head == WN_HEAD_CATEGORICAL) {

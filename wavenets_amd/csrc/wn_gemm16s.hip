@@ -16,6 +16,7 @@
 // Measured: configs[1] (K = 1920) 294 -> 270 us, configs[3] (K = 3840) 0.73 -> 0.71 ms: the pipeline was not what held this
 // contraction back (two k-steps of operands per wave in flight are right at bandwidth x latency).
 #include "wn_stream.h"
+#include "wn_sample.h"
 
 using namespace wn_stream;
 
@@ -44,6 +45,12 @@ struct GS {
 // SHIFT: the planes are the taps of a dilated conv over ONE tensor (plane_stride 0): plane p reads row t - a.shift[p] of the
 // same utterance, rows outside [0, T) contribute zero (src/layers.py:66-88 causal padding; negative shifts: its backward).
 // JT = 2 serves 32 and 64 output channels (a.N; a 32-channel image is padded to two row tiles, see wn_gemm_rows16_ok).
+// -3: the categorical head's last conv with the loss as its epilogue (RT = 1, JT = 8: 256 classes): a lane holds HALF a
+// row of logits in its 128 accumulator registers -- class 32 j + 8 (r >> 2) + 4 h + (r & 3) in register r of tile j, the
+// other half in lane ^ 32 -- so softmax, the clipped cross entropy of src/model.py:515-516, its gradient and the
+// sample_waveform draw are register loops plus a handful of exchanges with the partner lane, for 32 rows at once; the
+// one-row-per-wave loss kernel spends ~300 wave instructions per ROW on the same arithmetic (wn_cat_loss256_kernel: VALU
+// bound at 105 us for 268 MB) and needs the logits written (131 MB) and read back (131 MB).
 template <int RT, int JT_, int ACT, bool SHIFT = false>
 __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesArgs a) {
   using C = GS<RT, JT_>;
@@ -200,6 +207,137 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
 
     // ---- bias, activation, range guard, staged row stores ----
     const unsigned voff = (unsigned)(lane >> 3) * (unsigned)(a.ldy * 4) + (unsigned)(lane & 7) * 16u;
+    if constexpr (ACT == -3) {
+      static_assert(ACT != -3 || (RT == 1 && JT == 8), "the loss epilogue is the 256-class form");
+      const int rows_valid = live ? max(0, min(32, a.T - t0)) : 0;
+      const bool rok = xok[0];
+      const int64_t row = row0 + tl;
+      int tgt = rok ? a.target[row] : 0;
+      tgt = tgt < 0 ? 0 : (tgt > 255 ? 255 : tgt);
+      auto xch = [](float v) { return __shfl_xor(v, 32); };       // the partner lane holds the row's other 128 classes
+      // logits = acc + bias; row maximum
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + 32 * j + 8 * rq + 4 * h);
+          acc[0][j][4 * rq + 0] += bv.x; acc[0][j][4 * rq + 1] += bv.y; acc[0][j][4 * rq + 2] += bv.z; acc[0][j][4 * rq + 3] += bv.w;
+          m = fmaxf(fmaxf(m, fmaxf(acc[0][j][4 * rq + 0], acc[0][j][4 * rq + 1])), fmaxf(acc[0][j][4 * rq + 2], acc[0][j][4 * rq + 3]));
+        }
+      m = fmaxf(m, xch(m));
+      // e = exp(l - m) in place, per column tile (32 contiguous classes) so that the draw below can reuse the tile sums
+      float tsum[JT];
+      float z = 0.f;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        float ts = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][j][r] = expf(acc[0][j][r] - m); ts += acc[0][j][r]; }
+        ts += xch(ts);                                    // (commutative: both lanes of a row hold the same tile sum)
+        tsum[j] = ts;
+        z += ts;
+      }
+      const float inv = 1.0f / z;
+      // ---- sample_waveform(pred) of the row: inverse CDF over the classes in order (src/model.py:405-411), the draw
+      // wn_draw_cat_row makes from these probabilities up to the rounding of its running sums ----
+      if (a.sample_out) {
+        uint32_t rnd[4];
+        wn_philox((uint64_t)row, a.offset, a.seed, rnd);
+        const float thr = wn_u01(rnd[0]) * (z * inv);     // target mass in probability units (total = sum of q)
+        // column tile that holds the crossing
+        float run = 0.f, before = 0.f;
+        int jsel = JT - 1;
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const float nxt = run + tsum[j] * inv;
+          if (!found && nxt > thr) { found = true; jsel = j; before = run; }
+          run = nxt;
+        }
+        // this lane's 16 probabilities of that tile (a select chain: the tile index differs from row to row)
+        float qv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[0][0][r];
+#pragma unroll
+          for (int j = 1; j < JT; ++j) v = jsel == j ? acc[0][j][r] : v;
+          qv[r] = v * inv;
+        }
+        // groups of four contiguous classes in class order: k = 2 rq + h; this lane owns the groups with its h and gets
+        // the partner's sums.  Both lanes walk the same sums in the same order, so they agree on the crossing group.
+        float gown[4], goth[4];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          gown[rq] = (qv[4 * rq] + qv[4 * rq + 1]) + (qv[4 * rq + 2] + qv[4 * rq + 3]);
+          goth[rq] = xch(gown[rq]);
+        }
+        int kstar = 7;
+        float runb = before, rr = before;
+        bool fk = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float gk = ((k & 1) == h) ? gown[k >> 1] : goth[k >> 1];
+          const float nxt = rr + gk;
+          if (!fk && nxt > thr) { fk = true; kstar = k; runb = rr; }
+          rr = nxt;
+        }
+        const int rqs = kstar >> 1;
+        float r_ = runb;
+        int es = 3;
+        bool fe = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ve = rqs == 0 ? qv[e] : (rqs == 1 ? qv[4 + e] : (rqs == 2 ? qv[8 + e] : qv[12 + e]));
+          r_ += ve;
+          if (!fe && r_ > thr) { fe = true; es = e; }
+        }
+        const int mine = 32 * jsel + 8 * rqs + 4 * h + es;       // meaningful in the lane that owns group kstar
+        const int theirs = __shfl_xor(mine, 32);
+        const int drawn = ((kstar & 1) == h) ? mine : theirs;
+        if (rok && h == 0) a.sample_out[row] = (float)drawn * a.inv_lv - 1.0f;
+      }
+      // ---- clipped probabilities: S = sum clip(q), A = sum of the q inside the clip range, the target's q ----
+      float S = 0.f, A = 0.f, qt = 0.f;
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float q = acc[0][j][r] * inv;
+          acc[0][j][r] = q;
+          S += fminf(fmaxf(q, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+          if (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) A += q;
+          if (32 * j + 8 * (r >> 2) + 4 * h + (r & 3) == tgt) qt = q;
+        }
+      S += xch(S);
+      A += xch(A);
+      qt += xch(qt);                                      // (the other half contributes 0)
+      const float pt = fminf(fmaxf(qt, WN_KERAS_EPS), 1.0f - WN_KERAS_EPS);
+      const float ct = (qt >= WN_KERAS_EPS && qt <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+      if (rok && h == 0) a.loss_rows[row] = -(logf(pt) - logf(S));
+      // ---- gradient w.r.t. the logits, in place ----
+      const float invS = 1.0f / S;
+      const float dot = A * invS - ct * qt / pt;          // sum_j g_j q_j
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float q = acc[0][j][r];
+          const float c = (q >= WN_KERAS_EPS && q <= 1.0f - WN_KERAS_EPS) ? 1.f : 0.f;
+          float g = c * invS;
+          if (32 * j + 8 * (r >> 2) + 4 * h + (r & 3) == tgt) g -= ct / pt;
+          const float gl = a.gscale * q * (g - dot);
+          acc[0][j][r] = gl;
+          if (rok) wmax = fmaxf(wmax, fabsf(gl));
+        }
+        if (rows_valid > 0) {
+          float* dst = a.y + row0 * a.ldy + 32 * j;
+          if (rows_valid == 32) store_tile<PITCH, true>(acc[0][j], stage, dst, voff, (unsigned)(a.ldy * 4), rows_valid, lane);
+          else store_tile<PITCH, false>(acc[0][j], stage, dst, voff, (unsigned)(a.ldy * 4), rows_valid, lane);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int rows_valid = live ? max(0, min(32, a.T - (t0 + 32 * rt))) : 0;
@@ -241,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void wn_gemm_planes16s_kernel(WnGemmPlanesA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead k-steps land before the LDS is given back
   if (a.absmax_out) {
     wmax = wn_wave_absmax_bits(wmax);
-    if (lane == 0) { if (ACT == -2) wn_absmax_publish(a.absmax_out, wmax); else wn_absmax_publish_any(a.absmax_out, wmax); }
+    if (lane == 0) { if (ACT == -2 || ACT == -3) wn_absmax_publish(a.absmax_out, wmax); else wn_absmax_publish_any(a.absmax_out, wmax); }
   }
 }
 
@@ -281,6 +419,9 @@ int wn_launch_gemm_planes16s(const WnGemmPlanesArgs& a, hipStream_t s) {
       case WN_ACT_LEAKY_RELU: WN_GS_LAUNCH_S(WN_ACT_LEAKY_RELU); break;
       default: WN_GS_LAUNCH_S(-1); break;
     }
+  } else if (a.cat_loss) {
+    if (a.N != 256 || a.bwd || !a.target || !a.loss_rows || !a.y) { wn_set_error("gemm_planes16s: the loss epilogue is the 256-class forward form"); return WN_E_UNSUPPORTED; }
+    WN_GS_LAUNCH(1, 8, -3);
   } else if (a.bwd) {
     if (a.N == 256) WN_GS_LAUNCH(1, 8, -2);
     else WN_GS_LAUNCH(2, 4, -2);

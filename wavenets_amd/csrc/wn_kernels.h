@@ -92,6 +92,17 @@ struct WnGemmPlanesArgs {
   // nshift == nplanes (<= 4) with plane_stride 0: plane p reads row t - shift[p] of its utterance (the taps of a dilated
   // conv, or of its backward with negative shifts); rows outside [0, T) contribute zero.  Outputs of 32 / 64 channels only.
   int32_t nshift; int32_t shift[4];
+  // cat_loss != 0 (N == 256 == classes, forward form): the epilogue is the categorical loss instead of a store of the
+  // logits -- Keras sparse CE on clipped probabilities per row (src/model.py:515-516) into loss_rows, d loss / d logits
+  // (* gscale) into y, its running max-abs into absmax_out (a gradient slot), and optionally the step's
+  // sample_waveform(pred) draw (src/model.py:338,405-411) into sample_out: the (rows, 256) logits never reach HBM
+  int32_t cat_loss;
+  const int32_t* target;   // [rows] class indices
+  float gscale;
+  float* loss_rows;        // [rows]
+  float* sample_out;       // [rows] or null
+  float inv_lv;            // 2 / levels
+  uint64_t seed, offset;   // Philox key / counter word of the draw
 };
 int wn_gemm_planes16s_supported(int N, int plane_k, int nplanes, int ld, int ldy);
 int wn_gemm_taps16s_supported(int N, int plane_k, int ntaps, int ld, int ldy);

@@ -331,13 +331,23 @@ int wgrad(const float* x, int ldx, int K, int shift, const float* g, int ldg, in
 int block_forward(const BlockPtrs& k, const BlockBufs& f, hipStream_t s);
 int block_backward(const BlockPtrs& k, const BlockBufs& f, const BlockGrads& g, hipStream_t s);
 // ---- wn_forward.hip ----
+// Training passes of a 256-class categorical head: the loss runs as the epilogue of the head's last conv
+// (wn_gemm_planes16s_kernel<1, 8, -3>): where that launch puts its results.  forward_core sets `done` when it took the
+// fused path (the logits are then never written); loss_stage only sums the row losses.
+struct LossFuse {
+  const int32_t* target; float gscale; float* loss_rows; float* g_logits; float* absmax_out;
+  float* sample_out; float inv_lv; uint64_t seed, offset;
+  bool done;
+};
+bool loss_fusable(const wn_plan* p, int64_t rows);
 BlockPtrs block_ptrs(const wn_plan* p, int b, const float* params, const float* fragbase, int B, int T);
 void deep16_ptrs(const wn_plan* p, int b, const float* fragbase, BlockPtrs& k);
 int forward_core(wn_plan* p, const float* params, const float* x, bool prep, const float* cond, int B,
-                 int T, bool training, float* ws, const WsLayout& L, hipStream_t s, const GenRings* rings = nullptr);
+                 int T, bool training, float* ws, const WsLayout& L, hipStream_t s, const GenRings* rings = nullptr,
+                 LossFuse* lf = nullptr);
 // inputs = x[:, :-1], y_true = x[:, 1:]  (src/model.py:319-321)
 int shift_split(const float* x_full, int B, int T, float* inputs, float* y_true, hipStream_t s);
 int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float* ws, const WsLayout& L,
-               float* loss_out, float* absmax_out, hipStream_t s);
+               float* loss_out, float* absmax_out, hipStream_t s, bool fused_done = false);
 
 }  // namespace wnp

@@ -258,11 +258,28 @@ struct TrainCall {
     int rc;
     { const int rcs = shift_split(x_full, B, T, inputs, ws + L.yt, s); if (rcs) return rcs; }
     if (p->phase_on) (void)hipEventRecord(p->phase_ev[0], s);
-    rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s);
-    if (rc) return rc;
-    if (p->phase_on) (void)hipEventRecord(p->phase_ev[1], s);
+    // (zeroed before the forward pass: a fused loss epilogue publishes the max-abs of d loss / d logits from there)
     WN_HIP_CHECK(hipMemsetAsync(am, 0, L.n_absmax * sizeof(float), s));
-    rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s);
+    // 256-class categorical head: the loss rides in the head's last conv (LossFuse) unless the caller wants the probabilities
+    LossFuse lf;
+    memset(&lf, 0, sizeof(lf));
+    const bool fuse = !pred_out && loss_fusable(p, rows);
+    if (fuse) {
+      rc = wn_launch_quantize(ws + L.yt, reinterpret_cast<int32_t*>(ws + L.target), rows, p->c.bits, s);
+      if (rc) return rc;
+      lf.target = reinterpret_cast<const int32_t*>(ws + L.target);
+      lf.gscale = 1.0f / (float)global_batch;          // compute_average_loss, src/model.py:328-329
+      lf.loss_rows = ws + L.loss_rows; lf.g_logits = ws + L.GF.back(); lf.absmax_out = am_GF(nf - 1);
+      if (p->step_sample && !p->step_sample_det) {     // the armed sample_waveform(pred) draw of the step (src/model.py:338)
+        lf.sample_out = p->step_sample; lf.inv_lv = 1.0f / (float)(1 << (p->c.bits - 1));
+        lf.seed = p->step_sample_seed; lf.offset = p->step_sample_off;
+      }
+    }
+    rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s, nullptr, fuse ? &lf : nullptr);
+    if (rc) return rc;
+    if (lf.done && lf.sample_out) p->step_sample = nullptr;     // drawn
+    if (p->phase_on) (void)hipEventRecord(p->phase_ev[1], s);
+    rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s, lf.done);
     if (rc) return rc;
     if (pred_out) {
       if (p->c.head == WN_HEAD_CATEGORICAL) rc = wn_launch_softmax(ws + L.logits, pred_out, rows, p->Cout, s);
