@@ -359,6 +359,7 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     acc = [0.0] * 7
     nph = 3
+    mse_metric = MeanSquaredError()
     for _ in range(nph):
       ev[0].record()
       loss_p, samp_p, y_p = model.loss_and_grads(x, want_sample=True)   # the sample draw rides in the loss phase
@@ -367,7 +368,7 @@ def main():
       ev[2].record()
       model.optimizer.apply_gradients(model)
       ev[3].record()
-      mse_p = torch.mean((y_p - samp_p) ** 2)
+      mse_p = mse_metric.update_state_device(y_p, samp_p)      # the library's reduction, as train_step queues it
       ev[4].record()
       torch.cuda.synchronize()
       ms4 = (C.c_float * 4)()

@@ -89,12 +89,8 @@ __global__ __launch_bounds__(512, 2) void wn_bwd_pair_kernel(WnBwdPairArgs a) {
   const int tl = lane & 31, h = lane >> 5;
   float* stage = reinterpret_cast<float*>(smem + BP_W1 + BP_W2 + wave * BP_STAGE);
   {
-    const f32x4* s1 = reinterpret_cast<const f32x4*>(a.wx16);
-    const f32x4* s2 = reinterpret_cast<const f32x4*>(a.wu16);
-    f32x4* d1 = reinterpret_cast<f32x4*>(smem);
-    f32x4* d2 = reinterpret_cast<f32x4*>(smem + BP_W1);
-    for (int i = tid; i < BP_W1 / 16; i += 512) d1[i] = s1[i];
-    for (int i = tid; i < BP_W2 / 16; i += 512) d2[i] = s2[i];
+    // both images in ONE round trip (wn_images_to_lds: every load in flight before the first LDS store)
+    wn_images_to_lds<512, BP_W1 / 16, BP_W2 / 16>(a.wx16, smem, BP_W1 / 16, a.wu16, smem + BP_W1, BP_W2 / 16, tid);
   }
   __syncthreads();
   const bp_h8* w1 = reinterpret_cast<const bp_h8*>(smem) + lane;

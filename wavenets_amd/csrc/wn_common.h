@@ -147,6 +147,31 @@ __device__ __forceinline__ float wn_wave_absmax_bits(float wmax) {
   return v < 3.0e38f ? v : 3.0e38f;
 }
 
+// Weight image(s) global -> LDS at the top of a kernel whose weights stay resident: EVERY 16-byte load of the calling thread
+// is in flight before its first LDS store.  (Written as `for (i = tid; i < n; i += THREADS) dst[i] = src[i]` per image, hipcc
+// batches the first seven loads and then runs the rest -- the eighth piece, every piece of a second image, each bias vector --
+// as dependent load -> s_waitcnt vmcnt(0) -> ds_write round trips: six global round trips in front of the first tile of
+// the fused forward block kernel, ~6 of its 35 us per launch.)  N16_* = compile-time upper bounds of the 16-byte pieces.
+template <int THREADS, int MAX1, int MAX2 = 0>
+__device__ __forceinline__ void wn_images_to_lds(const void* src1, void* dst1, int n16_1, const void* src2, void* dst2, int n16_2,
+                                                 int tid) {
+  constexpr int K1 = (MAX1 + THREADS - 1) / THREADS, K2 = (MAX2 + THREADS - 1) / THREADS;
+  const f32x4* s1 = reinterpret_cast<const f32x4*>(src1);
+  const f32x4* s2 = reinterpret_cast<const f32x4*>(src2);
+  f32x4 v1[K1 > 0 ? K1 : 1], v2[K2 > 0 ? K2 : 1];
+#pragma unroll
+  for (int k = 0; k < K1; ++k) { const int i = tid + k * THREADS; if (i < n16_1) v1[k] = s1[i]; }
+#pragma unroll
+  for (int k = 0; k < K2; ++k) { const int i = tid + k * THREADS; if (i < n16_2) v2[k] = s2[i]; }
+  __builtin_amdgcn_sched_barrier(0);                   // keep the loads in front of the stores
+  f32x4* d1 = reinterpret_cast<f32x4*>(dst1);
+  f32x4* d2 = reinterpret_cast<f32x4*>(dst2);
+#pragma unroll
+  for (int k = 0; k < K1; ++k) { const int i = tid + k * THREADS; if (i < n16_1) d1[i] = v1[k]; }
+#pragma unroll
+  for (int k = 0; k < K2; ++k) { const int i = tid + k * THREADS; if (i < n16_2) d2[i] = v2[k]; }
+}
+
 // Keras clips probabilities to [eps, 1 - eps] before the cross entropy (backend.epsilon())
 #define WN_KERAS_EPS 1e-7f
 

@@ -708,9 +708,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_rows16_resident_kernel(WnGemmA
   float* stage = reinterpret_cast<float*>(smem + G::MAX_W_BYTES + wave * G::STAGE_BYTES);
   {
     const int n16 = nks_total * JT * 128;                // 16-byte pieces of the image (JTtot == JT)
-    const f32x4* src = reinterpret_cast<const f32x4*>(w16);
-    f32x4* dst = reinterpret_cast<f32x4*>(smem);
-    for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+    // (every load in flight before the first LDS store: wn_images_to_lds)
+    wn_images_to_lds<512, G::MAX_W_BYTES / 16>(w16, smem, n16, nullptr, nullptr, 0, tid);
   }
   __syncthreads();
   const h8* wl = reinterpret_cast<const h8*>(smem) + lane;

@@ -100,16 +100,14 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
 
   // ---- weights: global (fp16 hi|lo images) -> LDS, once per workgroup ----
   {
-    const f32x4* gd = reinterpret_cast<const f32x4*>(a.frag_d);
-    const f32x4* gr = reinterpret_cast<const f32x4*>(a.frag_r);
-    f32x4* sd = reinterpret_cast<f32x4*>(smem);
-    f32x4* sr = reinterpret_cast<f32x4*>(smem + G::WD_BYTES);
-    for (int i = tid; i < G::WD_BYTES / 16; i += 512) sd[i] = gd[i];
-    for (int i = tid; i < G::WR_BYTES / 16; i += 512) sr[i] = gr[i];
-    // the biases too: per tile they would be 6 * (R + D) / 32 global loads whose results are needed at once
+    // the biases too: per tile they would be 6 * (R + D) / 32 global loads whose results are needed at once.  Requested
+    // first, so that they travel with the image loads (one round trip for everything, see wn_images_to_lds)
     float* sb = reinterpret_cast<float*>(smem + G::WD_BYTES + G::WR_BYTES + G::WAVES * G::STAGE_BYTES);
-    for (int i = tid; i < 2 * D; i += 512) sb[i] = a.bias_d[i];
-    for (int i = tid; i < R; i += 512) sb[2 * D + i] = a.bias_r[i];
+    static_assert(2 * D + R <= 512, "one bias element per thread");
+    const float bval = tid < 2 * D ? a.bias_d[tid] : (tid < 2 * D + R ? a.bias_r[tid - 2 * D] : 0.f);
+    wn_images_to_lds<512, G::WD_BYTES / 16, G::WR_BYTES / 16>(a.frag_d, smem, G::WD_BYTES / 16, a.frag_r, smem + G::WD_BYTES,
+                                                               G::WR_BYTES / 16, tid);
+    if (tid < 2 * D + R) sb[tid] = bval;
   }
   __syncthreads();
   const float* lbias_d = reinterpret_cast<const float*>(smem + G::WD_BYTES + G::WR_BYTES + G::WAVES * G::STAGE_BYTES);
@@ -140,6 +138,10 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
 #pragma unroll
       for (int q = 0; q < QR; ++q) xq[tap][q] = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
     }
+    // Pin the requests HERE.  Without it hipcc's scheduler sinks most of them into the conv below, each right in front of its
+    // first use with s_waitcnt vmcnt(0) behind it (to shorten the live ranges of the 2 * R / 8 quads): the conv then walks
+    // six exposed global round trips per tile (found with s_memtime stamps: 8.1 k clocks for 96 MFMAs).
+    __builtin_amdgcn_sched_barrier(0);
     // ---- accumulators start at the bias (+ per-utterance conditioning bias) ----
     f32x16 u[JU];
 #pragma unroll
@@ -161,22 +163,35 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
     }
 
     // ---- dilated causal conv: KS1 k-steps of 16, 3 MFMAs per (k-step, tile) ----
-    wn_static_for<KS1>([&](auto sc) {
-      constexpr int ks = decltype(sc)::value;
-      constexpr int tap = ks / (R / 16), kk = ks % (R / 16);
-      f32x4 q0 = xq[tap][2 * kk], q1 = xq[tap][2 * kk + 1];
-      if (!xvalid[tap]) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
-      h8 bh, bl;
-      wn_split8(q0, q1, bh, bl);
+    // The weight fragments come out of LDS through a register ring two (k-step, tile) blocks ahead, pinned with
+    // sched_barrier: left to itself hipcc reads each fragment right in front of its products (ds_read, s_waitcnt lgkmcnt(0),
+    // MFMA: ~130 clocks of LDS latency in front of every 96 clocks of matrix work; s_memtime stamps: 8.1 k clocks for a
+    // tile's 96 products, and a wave's phases are latency chains that a partner wave does not fill).
+    {
+      constexpr int NB = KS1 * JU;                       // (k-step, tile) blocks in consumption order
+      h8 fr[3][2];
 #pragma unroll
-      for (int j = 0; j < JU; ++j) {
-        const h8 ah = wd[((ks * JU + j) * 2 + 0) * 64];
-        const h8 al = wd[((ks * JU + j) * 2 + 1) * 64];
-        u[j] = wn_mfma16(al, bh, u[j]);
-        u[j] = wn_mfma16(ah, bl, u[j]);
-        u[j] = wn_mfma16(ah, bh, u[j]);
-      }
-    });
+      for (int i = 0; i < 2; ++i) { fr[i][0] = wd[(i * 2 + 0) * 64]; fr[i][1] = wd[(i * 2 + 1) * 64]; }
+      h8 bh, bl;
+      wn_static_for<NB>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value;
+        constexpr int ks = blk / JU, j = blk % JU;
+        if constexpr (j == 0) {
+          constexpr int tap = ks / (R / 16), kk = ks % (R / 16);
+          f32x4 q0 = xq[tap][2 * kk], q1 = xq[tap][2 * kk + 1];
+          if (!xvalid[tap]) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+          wn_split8(q0, q1, bh, bl);
+        }
+        if constexpr (blk + 2 < NB) {
+          fr[(blk + 2) % 3][0] = wd[((blk + 2) * 2 + 0) * 64];
+          fr[(blk + 2) % 3][1] = wd[((blk + 2) * 2 + 1) * 64];
+        }
+        u[j] = wn_mfma16(fr[blk % 3][1], bh, u[j]);
+        u[j] = wn_mfma16(fr[blk % 3][0], bl, u[j]);
+        u[j] = wn_mfma16(fr[blk % 3][0], bh, u[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
 
     // ---- gate; a / g tiles reuse the accumulator registers ----
     //      u[j] (filter) -> z, u[j + D32] (gate) -> sigmoid; tanh kept in a separate tile set only
@@ -218,23 +233,32 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
         const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias_r + 32 * j + 8 * rq + 4 * h);
         o[j][4 * rq + 0] = bv.x; o[j][4 * rq + 1] = bv.y; o[j][4 * rq + 2] = bv.z; o[j][4 * rq + 3] = bv.w;
       }
-    wn_static_for<KS2>([&](auto sc) {
-      constexpr int ks = decltype(sc)::value;
-      constexpr int jz = ks / 2, r0 = 8 * (ks % 2);
-      f32x4 q0, q1;
-      q0.x = u[jz][r0 + 0]; q0.y = u[jz][r0 + 1]; q0.z = u[jz][r0 + 2]; q0.w = u[jz][r0 + 3];
-      q1.x = u[jz][r0 + 4]; q1.y = u[jz][r0 + 5]; q1.z = u[jz][r0 + 6]; q1.w = u[jz][r0 + 7];
-      h8 bh, bl;
-      wn_split8(q0, q1, bh, bl);
+    {
+      constexpr int NB = KS2 * R32;                      // the same fragment ring as in the conv
+      h8 fr[3][2];
 #pragma unroll
-      for (int j = 0; j < R32; ++j) {
-        const h8 ah = wr[((ks * R32 + j) * 2 + 0) * 64];
-        const h8 al = wr[((ks * R32 + j) * 2 + 1) * 64];
-        o[j] = wn_mfma16(al, bh, o[j]);
-        o[j] = wn_mfma16(ah, bl, o[j]);
-        o[j] = wn_mfma16(ah, bh, o[j]);
-      }
-    });
+      for (int i = 0; i < 2 && i < NB; ++i) { fr[i][0] = wr[(i * 2 + 0) * 64]; fr[i][1] = wr[(i * 2 + 1) * 64]; }
+      h8 bh, bl;
+      wn_static_for<NB>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value;
+        constexpr int ks = blk / R32, j = blk % R32;
+        if constexpr (j == 0) {
+          constexpr int jz = ks / 2, r0 = 8 * (ks % 2);
+          f32x4 q0, q1;
+          q0.x = u[jz][r0 + 0]; q0.y = u[jz][r0 + 1]; q0.z = u[jz][r0 + 2]; q0.w = u[jz][r0 + 3];
+          q1.x = u[jz][r0 + 4]; q1.y = u[jz][r0 + 5]; q1.z = u[jz][r0 + 6]; q1.w = u[jz][r0 + 7];
+          wn_split8(q0, q1, bh, bl);
+        }
+        if constexpr (blk + 2 < NB) {
+          fr[(blk + 2) % 3][0] = wr[((blk + 2) * 2 + 0) * 64];
+          fr[(blk + 2) % 3][1] = wr[((blk + 2) * 2 + 1) * 64];
+        }
+        o[j] = wn_mfma16(fr[blk % 3][1], bh, o[j]);
+        o[j] = wn_mfma16(fr[blk % 3][0], bl, o[j]);
+        o[j] = wn_mfma16(fr[blk % 3][0], bh, o[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
 
     if (rows_valid > 0) {
       if (a.o_out) wn_store_tile<R32, PITCH>(o, stage, a.o_out + row0 * R, R, rows_valid, lane);
