@@ -13,7 +13,9 @@
 // so the four rows one transposed read touches fall on four different bank quarters.
 //
 // One workgroup of 8 waves per (block, utterance, time range); chunks of 32 time steps (two MFMA k-steps), two LDS
-// stages, one barrier per chunk: the next chunk's rows are in registers while this chunk's 48 products per wave run.
+// stages, one barrier per chunk: the rows of the next TWO chunks are in registers (two register sets, each stored to its
+// stage and re-requested at once) while this chunk's 48 products per wave run -- a request then has two product phases
+// (~1.5 us) to land instead of one: with one chunk in flight the kernel waited on every chunk (3.5-4.0 TB/s).
 // Wave w owns output row tiles {2 (w & 3), +1} x column tiles {4 (w >> 2) .. +3}: 8 accumulator tiles.
 #include <hip/hip_fp16.h>
 
@@ -113,40 +115,50 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
   const bool upper = G2 && gc >= NC / 2;                 // this thread's g piece belongs to the second tensor
   const float* gbase = upper ? ws + J.g2_off + (int64_t)ub * T * LDG + (gc - NC / 2) : ws + J.g_off + (int64_t)ub * T * LDG + gc;
   const float gs_t = upper ? gsc2 : gsc;
-  f32x4 xs[TAPS][XP], gv[GP];                            // the chunk in flight: x[t - shift] (| x[t]), g
+  struct Regs { f32x4 xs[TAPS][XP]; f32x4 gv[GP]; };     // one chunk in flight: x[t - shift] (| x[t]), g
+  Regs ra, rb;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  auto load = [&](int t0) {
-    const bool interior = (t0 + WT_ROWS <= r1) && (t0 - d >= 0);       // workgroup-uniform: no row masks
+  // Every request is UNCONDITIONAL (row index clamped into the utterance, rows outside the range zeroed when the chunk is
+  // stored): the number of loads per iteration is then a constant and hipcc can wait for the OLDER register set with a
+  // counted vmcnt(N) while the younger one stays in flight (behind a conditional load it falls back to vmcnt(0)).
+  auto load = [&](int t0, Regs& q) {
+    f32x4 (&xs)[TAPS][XP] = q.xs;
+    f32x4 (&gv)[GP] = q.gv;
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
       const int t = t0 + xr + XRP * k;
+      const int tc = min(t, T - 1);
       if (XSEG > 0) {
-        xs[0][k] = (xvalid && (interior || t < r1)) ? wt_ldg4(xbase + (int64_t)t * LDX) : zero4;
-      } else if (interior) {
-        xs[0][k] = wt_ldg4(xbase + (int64_t)(t - d) * LDX);
-        if constexpr (TAPS == 2) xs[1][k] = wt_ldg4(xbase + (int64_t)t * LDX);
+        xs[0][k] = wt_ldg4(xbase + (int64_t)tc * LDX);
       } else {
-        xs[0][k] = (t < r1 && t - d >= 0) ? wt_ldg4(xbase + (int64_t)(t - d) * LDX) : zero4;
-        if constexpr (TAPS == 2) xs[1][k] = t < r1 ? wt_ldg4(xbase + (int64_t)t * LDX) : zero4;
+        xs[0][k] = wt_ldg4(xbase + (int64_t)max(tc - d, 0) * LDX);
+        if constexpr (TAPS == 2) xs[1][k] = wt_ldg4(xbase + (int64_t)tc * LDX);
       }
     }
 #pragma unroll
     for (int k = 0; k < GP; ++k) {
-      const int t = t0 + gr + GRP * k;
-      gv[k] = (interior || t < r1) ? wt_ldg4(gbase + (int64_t)t * LDG) : zero4;
+      const int t = min(t0 + gr + GRP * k, T - 1);
+      gv[k] = wt_ldg4(gbase + (int64_t)t * LDG);
     }
   };
-  auto store = [&](int stage) {
+  auto store = [&](int stage, const Regs& q, int t0) {
+    const f32x4 (&xs)[TAPS][XP] = q.xs;
+    const f32x4 (&gv)[GP] = q.gv;
     unsigned char* st = smem + stage * STAGE;
+    const bool interior = (t0 + WT_ROWS <= r1) && (t0 - d >= 0);       // workgroup-uniform: no row masks
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
       unsigned char* row = st + (xr + XRP * k) * PITCH;
+      const int t = t0 + xr + XRP * k;
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp) {
         wt_h4 hi, lo;
-        wt_split4(xs[tp][k], 1.0f, hi, lo);
+        // (the first plane is the SHIFTED tap x[t - d] unless the rows are segments of an unshifted tensor)
+        const bool ok = interior || (t < r1 && (XSEG > 0 || (TAPS == 2 && tp == TAPS - 1) || t - d >= 0));
+        const f32x4 xv = (ok && xvalid) ? xs[tp][k] : zero4;
+        wt_split4(xv, 1.0f, hi, lo);
         *reinterpret_cast<wt_h4*>(row + (tp * KC + xc) * 2) = hi;
         *reinterpret_cast<wt_h4*>(row + PLANE + (tp * KC + xc) * 2) = lo;
       }
@@ -155,8 +167,9 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
     for (int k = 0; k < GP; ++k) {
       wt_h4 hi, lo;
       unsigned char* row = st + (gr + GRP * k) * PITCH;
-      wt_split4(gv[k], gs_t, hi, lo);
-      bsum[0] += gv[k].x; bsum[1] += gv[k].y; bsum[2] += gv[k].z; bsum[3] += gv[k].w;
+      const f32x4 g4 = (interior || t0 + gr + GRP * k < r1) ? gv[k] : zero4;
+      wt_split4(g4, gs_t, hi, lo);
+      bsum[0] += g4.x; bsum[1] += g4.y; bsum[2] += g4.z; bsum[3] += g4.w;
       *reinterpret_cast<wt_h4*>(row + (XC + gc) * 2) = hi;
       *reinterpret_cast<wt_h4*>(row + PLANE + (XC + gc) * 2) = lo;
     }
@@ -199,19 +212,40 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_tr_kernel(const WnWgPair* job
     });
   };
 
-  // ---- pipeline: rows of the next chunk in registers, this chunk in LDS, one barrier per chunk ----
-  if (r0 < r1) {
-    load(r0);
-    store(0);
-    if (r0 + WT_ROWS < r1) load(r0 + WT_ROWS);
-  }
-  __syncthreads();
-  int st = 0;
-  for (int t0 = r0; t0 < r1; t0 += WT_ROWS, st ^= 1) {
-    if (t0 + WT_ROWS < r1) store(st ^ 1);                 // (registers hold chunk t0 + 32; its stage was read one barrier ago)
-    if (t0 + 2 * WT_ROWS < r1) load(t0 + 2 * WT_ROWS);
-    compute(st);
+  // ---- pipeline: this chunk in LDS, one barrier per chunk; the rows of the next two chunks in registers (ra, rb), or of
+  //      the next one only where two register sets do not fit beside the accumulators (both taps: 343 spilled VGPRs) ----
+  constexpr bool DEEP = TAPS == 1;
+  if constexpr (DEEP) {
+    load(r0, ra);
+    load(r0 + WT_ROWS, rb);
+    store(0, ra, r0);
+    load(r0 + 2 * WT_ROWS, ra);
     __syncthreads();
+    // invariant at the top of an iteration for chunk t0 (stage 0): rb holds chunk t0 + 32, ra holds chunk t0 + 64
+    for (int t0 = r0; t0 < r1; t0 += 2 * WT_ROWS) {
+      store(1, rb, t0 + WT_ROWS);                          // (its stage was read one barrier ago)
+      load(t0 + 3 * WT_ROWS, rb);
+      compute(0);
+      __syncthreads();
+      if (t0 + WT_ROWS >= r1) break;
+      // chunk t0 + 32 (stage 1): ra holds chunk t0 + 64, rb chunk t0 + 96
+      store(0, ra, t0 + 2 * WT_ROWS);
+      load(t0 + 4 * WT_ROWS, ra);
+      compute(1);
+      __syncthreads();
+    }
+  } else {
+    load(r0, ra);
+    store(0, ra, r0);
+    load(r0 + WT_ROWS, ra);
+    __syncthreads();
+    int st = 0;
+    for (int t0 = r0; t0 < r1; t0 += WT_ROWS, st ^= 1) {
+      store(st ^ 1, ra, t0 + WT_ROWS);                     // (registers hold chunk t0 + 32; its stage was read one barrier ago)
+      load(t0 + 2 * WT_ROWS, ra);
+      compute(st);
+      __syncthreads();
+    }
   }
 
   // ---- partial results -> this split's slab row (laid out like the flat gradient buffer; taps stacked along k) ----
