@@ -199,7 +199,10 @@ int64_t wn_generate_workspace_floats(const wn_plan* p, int32_t B, int32_t queued
  * |activation| at or beyond that limit: the priming pass (residual stream, skip sum, head activations), and in EVERY
  * queued step the residual stream and folded skip sum of the chain kernels, the per-block kernels, the skip contraction
  * and the hidden head activations.  (Below the limit it holds the priming pass's largest magnitude; the per-step kernels
- * only ever raise it past the limit.)  A tripped call is to be repeated with the exact-fp32 kernels (wn_debug_set(1, 1)). */
+ * only ever raise it past the limit.)  A tripped call is to be repeated with the exact-fp32 kernels (wn_debug_set(1, 1)).
+ * The 32-bit word right behind it (slot + 1) is the hand-off watchdog of the multi-workgroup generation step
+ * (wn_gen_relay128_kernel): zero after a good call; non-zero bits name a workgroup that gave up waiting for its
+ * predecessor's rows -- the samples of such a call are invalid and the caller must treat it as failed. */
 int64_t wn_generate_guard_slot(const wn_plan* p, int32_t B, int32_t queued);
 
 /* ---- WaveNetLayer.call, src/layers.py:178-224, standalone block ----

@@ -990,13 +990,18 @@ def test_queued_generation_ring_wraparound():
   assert torch.equal(naive, queued)
 
 
-@pytest.mark.parametrize('B,cond', [(3, False), (40, False), (5, True)])
-def test_queued_generation_128_channel_chain(B, cond):
-  """128-channel blocks: every block of a step, the input conv and the folded skip contraction in one launch
-  (wn_gen_chain128_kernel) -- one and two utterance tiles, rings that wrap, with and without global conditioning -- draws
-  the sliding window's samples."""
-  kw = dict(blocks=5, channels=128, skip_channels=256, dilation_bound=16, final_layers_channels=[128, 64],
-            activation='leaky_relu', bits=8)
+@pytest.mark.parametrize('form', ['relay', 'one_workgroup'])
+@pytest.mark.parametrize('B,cond,finals,skip', [(3, False, [128, 64], True), (40, False, [128, 64], True), (5, True, [128, 64], True),
+                                                (33, False, [64, 64], True), (4, False, [128, 64], False)])
+def test_queued_generation_128_channel_chain(B, cond, finals, skip, form):
+  """128-channel blocks: every block of a step, the input conv and the folded skip contraction in one launch -- as a relay
+  over one workgroup per block whose rows travel as tagged granules (wn_gen_relay128_kernel, the default) and inside one
+  workgroup per utterance tile (wn_gen_chain128_kernel, knob 2).  One and two utterance tiles, rings that wrap, with and
+  without global conditioning, a skip sum the chain cannot fold (64 columns) and no skip connections at all: each form
+  draws the sliding window's samples."""
+  from wavenets_amd import _lib
+  kw = dict(blocks=5, channels=128, skip_channels=256, dilation_bound=16, final_layers_channels=finals,
+            activation='leaky_relu', bits=8, use_skip=skip)
   if cond:
     kw.update(conditioning='global', mapping_layers=[8, 16], mapping_activation='leaky_relu', cond_inputs=7)
   ocfg, params, model = make_pair(seed=17, bias_range=0.3, **kw)
@@ -1006,8 +1011,37 @@ def test_queued_generation_128_channel_chain(B, cond):
   if cond:
     args['condition'] = c
   naive = model.generate(40, use_queues=False, **args)
-  queued = model.generate(40, use_queues=True, **args)
+  _lib.lib().wn_debug_set(2, 1 if form == 'one_workgroup' else 0)
+  try:
+    queued = model.generate(40, use_queues=True, **args)
+    again = model.generate(40, use_queues=True, **args)      # the granule tags of the first call are still in the workspace
+  finally:
+    _lib.lib().wn_debug_set(2, 0)
   assert torch.equal(naive, queued), (naive - queued).abs().max()
+  assert torch.equal(queued, again)
+
+
+def test_generation_relay_under_load_and_long_runs():
+  """The relay's hand-offs with the GPU busy on another stream (a large copy kernel loop competing for the CUs and the
+  fabric) and over many steps: 600 samples at 30 blocks of 128 channels, bit-identical to the one-workgroup form."""
+  from wavenets_amd import WaveNet, _lib
+  kw = dict(blocks=30, channels=128, skip_channels=256, dilation_bound=1024, final_layers_channels=[128, 256],
+            activation='leaky_relu', num_mixtures=10, sampling_function='logistic', bits=16)
+  model = WaveNet(**kw, device=dev(), seed=2)
+  w = O.synthetic_waveform(8, model.receptive_field, seed=5).to(dev())
+  _lib.lib().wn_debug_set(2, 1)
+  try:
+    ref = model.generate(600, sample=w, use_queues=True, deterministic=False)
+  finally:
+    _lib.lib().wn_debug_set(2, 0)
+  side = torch.cuda.Stream()
+  big = torch.empty(1 << 28, device=dev())
+  with torch.cuda.stream(side):
+    for _ in range(200):
+      big.mul_(1.0001)
+  got = model.generate(600, sample=w, use_queues=True, deterministic=False)
+  torch.cuda.synchronize()
+  assert torch.equal(ref, got)
 
 
 def test_plan_caches_survive_shape_changes():

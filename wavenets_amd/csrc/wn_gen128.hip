@@ -387,6 +387,393 @@ __global__ __launch_bounds__(512, 2) void wn_gen_chain128_kernel(WnGen128Args a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same step as a RELAY over workgroups: one workgroup per (block, utterance tile), all of them resident at once.
+//
+// wn_gen_chain128_kernel walks the blocks inside ONE workgroup, and every block starts with a cold round trip for its
+// 384 KiB of weight fragments through one CU (13 us a block: 0.39 ms a step, 2.5 k samples/s per utterance).  Here
+// workgroup b requests the fragments of ITS block the moment the launch starts -- all blocks at once, every CU its own
+// fetch path -- stages the older tap (written by an earlier launch) and runs that tap's half of the gated conv (k-steps
+// 0..7 come first in the summation order anyway) while the chain is still upstream.  Then it waits for its block input,
+// which workgroup b - 1 hands over through memory, finishes the block and hands its output on.  The skip accumulator
+// travels the same way between the waves 4..7 of consecutive workgroups (its summation order is block order), off the
+// critical path.  Per element the arithmetic is wn_gen_chain128_kernel's, operation for operation.
+//
+// Hand-off (guide: Guideline 16, form R2 "the data is the flag"): every handed-over fp32 value travels as one naturally
+// aligned 8-byte granule {value, epoch} written by ONE relaxed agent-scope (sc1, write-through) atomic store and read by
+// relaxed agent-scope atomic loads (sc1: past the reader's L1), re-read until every tag of the wave equals the launch's
+// epoch.  No flags, no fences.  Epoch = the step index inside the wn_generate call (>= 1); wn_generate zeroes the granule
+// area once per call.  A workgroup only ever waits for the workgroup before it, which has a smaller index and is
+// therefore dispatched no later: the chain drains whatever the residency.  Every wait is bounded: a reader that gives up
+// records the block in a.tmo and carries on with what it has (wn_generate reports the call as failed afterwards), so
+// the launch ends in any case.
+typedef __attribute__((address_space(1))) unsigned long long wn_gu64;
+#define WN_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define WN_RELAY_SPINS (1u << 18)
+
+namespace {
+
+__device__ __forceinline__ void granule_store(unsigned long long* g, unsigned epoch, float v) {
+  __hip_atomic_store((wn_gu64*)g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), WN_RLX_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* g) {
+  return __hip_atomic_load((wn_gu64*)g, WN_RLX_AGENT);
+}
+// Two granules side by side in one 16-byte access ({value, epoch, value, epoch}): each 8-byte half is a granule of its own
+// (a 16-byte sc1 access has never been seen to tear an aligned 8-byte half on gfx950; the halves are checked separately).
+// Buffer instructions with aux = 16 (sc1): half the requests of 8-byte atomics -- a request costs the issuing wave ~100
+// clocks and the sender's stores sit on the chain's critical path.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void granule2_store(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned epoch, float v0, float v1) {
+  const u32x4 q = {__float_as_uint(v0), epoch, __float_as_uint(v1), epoch};
+  __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)off, 0, 16);
+}
+__device__ __forceinline__ u32x4 granule2_load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+}
+__device__ __forceinline__ void relay_give_up(unsigned* tmo, int code, int lane) {
+  if (lane == 0) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)tmo, (unsigned)code, WN_RLX_AGENT);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a) {
+  constexpr int R = 128, D = 128, NK1 = 16, NK2 = 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NK1 * 2048 + 2 * 4 * 16 * 64 * 4];
+  f32x4* xs = reinterpret_cast<f32x4*>(smem);
+  float* gs = reinterpret_cast<float*>(smem + NK1 * 2048);
+  float* zs = gs + 4 * 16 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = lane & 31, h = lane >> 5;
+  const int b = (int)blockIdx.x / a.ntiles, tile = (int)blockIdx.x % a.ntiles;   // block-major: predecessors first
+  const int row = tile * 32 + tl;
+  const bool rok = row < a.B;
+  const unsigned epoch = a.epoch;
+  const bool skip_on = a.skip_w16_off >= 0;
+  const bool last = b + 1 == a.nblocks;
+  float wmax = 0.f;
+  // knob 24: s_memtime stamps of tile 0, [block][8]: 0 entry, 1 older tap staged, 2 older tap's products done, 3 input arrived,
+  // 4 z ready, 5 output handed on (wave 0); 6 skip accumulator arrived, 7 handed on (wave 4)
+#define RL_TS(w, k) do { if (a.ts && tile == 0 && tid == 64 * (w)) a.ts[b * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  RL_TS(0, 0);
+  const WnGenBlock g = a.blocks[b];
+  // granule areas of this workgroup's INPUT (written by block b - 1) and OUTPUT (read by block b + 1)
+  unsigned long long* const gbase = reinterpret_cast<unsigned long long*>(a.ws + a.relay_off);
+  auto xg_of = [&](int blk) { return gbase + ((int64_t)blk * a.ntiles + tile) * 8192; };            // [1024 pieces][4]
+  auto sg_of = [&](int blk) { return gbase + ((int64_t)(a.nblocks + blk) * a.ntiles + tile) * 8192 ; };   // [4][64][16] (+ pad)
+
+  // ---- every weight fragment of this wave, requested at once ----
+  const float* ring = a.ws + g.ring_off;
+  const float* xold = ring + (int64_t)((a.tau - g.dilation) % g.nslots) * a.B * R;
+  const float* xnew = ring + (int64_t)(a.tau % g.nslots) * a.B * R;
+  h8 wd[NK1][2];
+  {
+    const char* base = reinterpret_cast<const char*>(a.ws + g.w16d_off) + (int64_t)wave * 2048 + lane * 16;
+#pragma unroll
+    for (int c = 0; c < NK1; ++c) {
+      wd[c][0] = ldg_h8(base + c * 16384);
+      wd[c][1] = ldg_h8(base + c * 16384 + 1024);
+    }
+  }
+  h8 wr[NK2][2];                                       // waves 0..3: the 1x1's fragments; 4..7: the skip contraction's
+  if (wave < 4 || skip_on) {
+    const char* base = wave < 4 ? reinterpret_cast<const char*>(a.ws + g.w16r_off) + (int64_t)wave * 2048 + lane * 16
+                                : reinterpret_cast<const char*>(a.ws + a.skip_w16_off) + (int64_t)b * (NK2 * 8192) +
+                                      (int64_t)(wave - 4) * 2048 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < NK2; ++ks) {
+      wr[ks][0] = ldg_h8(base + ks * 8192);
+      wr[ks][1] = ldg_h8(base + ks * 8192 + 1024);
+    }
+  }
+  // ---- operand rows of the older tap (block 0: of both taps) -> LDS in B-fragment order ----
+  const int npieces = b == 0 ? 2048 : 1024;
+  for (int e = tid; e < npieces; e += 512) {
+    const int c = e >> 7, q = (e >> 6) & 1, l = e & 63;
+    const int r2 = tile * 32 + (l & 31);
+    const int ch0 = 16 * (c & 7) + 8 * q + 4 * (l >> 5);
+    const float* src = (c < 8 ? xold : xnew) + (int64_t)(r2 < a.B ? r2 : 0) * R + ch0;
+    f32x4 v;
+    if (c >= 8 && a.xin) {
+      // block 0's newest tap = the input causal conv of this step (see wn_gen_chain128_kernel)
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int tap = 0; tap < 2; ++tap) {
+        const float xv = a.xin[(int64_t)((a.tau - (1 - tap)) % 2) * a.B + (r2 < a.B ? r2 : 0)];
+        const f32x4 wv = ldg4(a.causal_w + (int64_t)tap * R + ch0);
+        a0 = fmaf(wv.x, xv, a0); a1 = fmaf(wv.y, xv, a1); a2 = fmaf(wv.z, xv, a2); a3 = fmaf(wv.w, xv, a3);
+      }
+      const f32x4 bv = ldg4(a.causal_b + ch0);
+      v = f32x4{a0 + bv.x, a1 + bv.y, a2 + bv.z, a3 + bv.w};
+      if (r2 < a.B) *reinterpret_cast<f32x4*>(a.ws + g.ring_off + (int64_t)(a.tau % g.nslots) * a.B * R + (int64_t)r2 * R + ch0) = v;
+    } else {
+      v = ldg4(src);
+    }
+    if (r2 >= a.B) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    xs[e] = v;
+  }
+  f32x16 u;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const f32x4 bv = ldg4(a.params + g.bias_d_off + 32 * wave + 8 * rq + 4 * h);
+    u[4 * rq + 0] = bv.x; u[4 * rq + 1] = bv.y; u[4 * rq + 2] = bv.z; u[4 * rq + 3] = bv.w;
+  }
+  if (g.cb_off >= 0) {
+    const float* cbp = a.ws + g.cb_off + (int64_t)(rok ? row : 0) * 2 * D + 4 * h + 32 * wave;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 cv = ldg4(cbp + 8 * rq);
+      u[4 * rq + 0] += cv.x; u[4 * rq + 1] += cv.y; u[4 * rq + 2] += cv.z; u[4 * rq + 3] += cv.w;
+    }
+  }
+  // (far down the chain: one lane watches the hand-off INTO the block before this one, so that the whole workgroup
+  // only starts polling when its own input is one block away -- 29 workgroups x 512 lanes re-reading their granules for
+  // the whole step would load the fabric the chain's own hand-offs travel on)
+  if (b >= 2 && tid == 0) {
+    const unsigned long long* w = xg_of(b - 1);
+    for (unsigned spins = 0; (unsigned)(granule_load(w) >> 32) != epoch; ) {
+      if (++spins > WN_RELAY_SPINS) { relay_give_up(a.tmo, b, 0); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  RL_TS(0, 1);
+  // ---- gated conv, older tap: k-steps 0..7 ----
+#pragma unroll
+  for (int c = 0; c < NK1 / 2; ++c) {
+    const f32x4 q0 = xs[(c * 2 + 0) * 64 + lane], q1 = xs[(c * 2 + 1) * 64 + lane];
+    h8 bh, bl;
+    split8(q0, q1, bh, bl);
+    u = mfma16(wd[c][1], bh, u);
+    u = mfma16(wd[c][0], bl, u);
+    u = mfma16(wd[c][0], bh, u);
+  }
+  RL_TS(0, 2);
+  // ---- the block input of this step, from block b - 1: pieces 1024..2047 (2 per thread, 4 granules each) ----
+  if (b > 0) {
+    const unsigned long long* xg = xg_of(b);
+    f32x4 v[2];
+    bool lv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 512 * i;
+      lv[i] = tile * 32 + (e & 31) < a.B;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(xg), 0, 65536, 0x00020000);
+    for (unsigned spins = 0;;) {
+      bool ok = true;
+      u32x4 q[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (lv[i]) {
+          q[i][0] = granule2_load(xrs, (unsigned)(tid + 512 * i) * 32u);
+          q[i][1] = granule2_load(xrs, (unsigned)(tid + 512 * i) * 32u + 16u);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (lv[i]) {
+          ok = ok && q[i][0].y == epoch && q[i][0].w == epoch && q[i][1].y == epoch && q[i][1].w == epoch;
+          v[i] = f32x4{__uint_as_float(q[i][0].x), __uint_as_float(q[i][0].z), __uint_as_float(q[i][1].x), __uint_as_float(q[i][1].z)};
+        }
+      }
+      if (__all(ok)) break;                            // wave-uniform
+      if (++spins > WN_RELAY_SPINS) { relay_give_up(a.tmo, 1000 + b, lane); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    RL_TS(0, 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xs[1024 + tid + 512 * i] = v[i];
+    __syncthreads();
+  }
+  // ---- gated conv, newest tap: k-steps 8..15 ----
+#pragma unroll
+  for (int c = NK1 / 2; c < NK1; ++c) {
+    const f32x4 q0 = xs[(c * 2 + 0) * 64 + lane], q1 = xs[(c * 2 + 1) * 64 + lane];
+    h8 bh, bl;
+    split8(q0, q1, bh, bl);
+    u = mfma16(wd[c][1], bh, u);
+    u = mfma16(wd[c][0], bl, u);
+    u = mfma16(wd[c][0], bh, u);
+  }
+  // the gate: waves 4..7 turn their tile into sigmoids while waves 0..3 turn theirs into tanh's, then one exchange
+  if (wave >= 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gs[((wave - 4) * 16 + r) * 64 + lane] = wn_sigmoid_fast(u[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r] = wn_tanh_fast(u[r]);
+  }
+  __syncthreads();
+  f32x4 bv4[4];
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sg = gs[(wave * 16 + r) * 64 + lane];
+      u[r] = u[r] * sg;
+      zs[(wave * 16 + r) * 64 + lane] = u[r];
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) bv4[rq] = ldg4(a.params + g.bias_r_off + 32 * wave + 8 * rq + 4 * h);
+  }
+  __syncthreads();
+  RL_TS(0, 4);
+  if (wave < 4) {
+    f32x16 o;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 bv = bv4[rq];
+      o[4 * rq + 0] = bv.x; o[4 * rq + 1] = bv.y; o[4 * rq + 2] = bv.z; o[4 * rq + 3] = bv.w;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK2; ++ks) {
+      const int jz = ks >> 1, r0 = 8 * (ks & 1);
+      f32x4 q0, q1;
+      q0.x = zs[(jz * 16 + r0 + 0) * 64 + lane]; q0.y = zs[(jz * 16 + r0 + 1) * 64 + lane];
+      q0.z = zs[(jz * 16 + r0 + 2) * 64 + lane]; q0.w = zs[(jz * 16 + r0 + 3) * 64 + lane];
+      q1.x = zs[(jz * 16 + r0 + 4) * 64 + lane]; q1.y = zs[(jz * 16 + r0 + 5) * 64 + lane];
+      q1.z = zs[(jz * 16 + r0 + 6) * 64 + lane]; q1.w = zs[(jz * 16 + r0 + 7) * 64 + lane];
+      h8 bh, bl;
+      split8(q0, q1, bh, bl);
+      o = mfma16(wr[ks][1], bh, o);
+      o = mfma16(wr[ks][0], bl, o);
+      o = mfma16(wr[ks][0], bh, o);
+    }
+    // residual = this lane's own pieces of the newest tap; the sum goes to block b + 1 as granules FIRST (its workgroup
+    // is waiting for them), then to that block's ring slot of this time step (read by later launches only)
+    unsigned long long* xgn = last ? nullptr : xg_of(b + 1);
+    float* dst = nullptr;
+    if (!last) {
+      const WnGenBlock gn = a.blocks[b + 1];
+      dst = a.ws + gn.ring_off + (int64_t)(a.tau % gn.nslots) * a.B * R;
+    } else if (a.hrow_off >= 0) {
+      dst = a.ws + a.hrow_off;
+    }
+    const __amdgpu_buffer_rsrc_t xnrs = __builtin_amdgcn_make_buffer_rsrc(xgn ? xgn : gbase, 0, 65536, 0x00020000);
+    f32x4 ov[4];
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      ov[rq].x = o[4 * rq + 0]; ov[rq].y = o[4 * rq + 1]; ov[rq].z = o[4 * rq + 2]; ov[rq].w = o[4 * rq + 3];
+      const int piece = ((8 + 2 * wave + (rq >> 1)) * 2 + (rq & 1)) * 64 + lane;
+      if (rok) wmax = wn_absmax_acc(wmax, ov[rq].x, ov[rq].y, ov[rq].z, ov[rq].w);
+      if (a.residual) {
+        const f32x4 rv = xs[piece];
+        if (rok) wmax = wn_absmax_acc(wmax, rv.x, rv.y, rv.z, rv.w);
+        ov[rq].x += rv.x; ov[rq].y += rv.y; ov[rq].z += rv.z; ov[rq].w += rv.w;
+      }
+      if (xgn && rok) {
+        granule2_store(xnrs, (unsigned)(piece - 1024) * 32u, epoch, ov[rq].x, ov[rq].y);
+        granule2_store(xnrs, (unsigned)(piece - 1024) * 32u + 16u, epoch, ov[rq].z, ov[rq].w);
+      }
+    }
+    RL_TS(0, 5);
+    if (dst && rok) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) *reinterpret_cast<f32x4*>(dst + (int64_t)row * R + 32 * wave + 8 * rq + 4 * h) = ov[rq];
+    }
+    if (rok) {                                          // gated activations of this block (later launches only)
+      float* zp = a.ws + a.zrow_off + ((int64_t)b * a.B + row) * D + 32 * wave + 4 * h;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 zv;
+        zv.x = u[4 * rq + 0]; zv.y = u[4 * rq + 1]; zv.z = u[4 * rq + 2]; zv.w = u[4 * rq + 3];
+        *reinterpret_cast<f32x4*>(zp + 8 * rq) = zv;
+      }
+    }
+  } else if (skip_on) {
+    // ---- folded skip contraction: the accumulator of column tile wave - 4 arrives from block b - 1 (same lane, same
+    //      register), takes this block's 24 products, and travels on (or, after the last block, through the epilogue of
+    //      wn_gemm_planes16s_kernel) ----
+    const int j = wave - 4;
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    if (b > 0 && rok) {
+      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(sg_of(b), 0, 65536, 0x00020000);
+      const unsigned soff = (unsigned)(j * 64 + lane) * 128u;
+      for (unsigned spins = 0;;) {
+        bool ok = true;
+        u32x4 q[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) q[r] = granule2_load(srs, soff + 16u * r);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          ok = ok && q[r].y == epoch && q[r].w == epoch;
+          sacc[2 * r] = __uint_as_float(q[r].x);
+          sacc[2 * r + 1] = __uint_as_float(q[r].z);
+        }
+        if (ok) break;                                  // (per lane: the lanes of a wave leave the loop one by one)
+        if (++spins > WN_RELAY_SPINS) { relay_give_up(a.tmo, 2000 + b, 0); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    RL_TS(4, 6);
+#pragma unroll
+    for (int ks = 0; ks < NK2; ++ks) {
+      const int jz = ks >> 1, r0 = 8 * (ks & 1);
+      f32x4 q0, q1;
+      q0.x = zs[(jz * 16 + r0 + 0) * 64 + lane]; q0.y = zs[(jz * 16 + r0 + 1) * 64 + lane];
+      q0.z = zs[(jz * 16 + r0 + 2) * 64 + lane]; q0.w = zs[(jz * 16 + r0 + 3) * 64 + lane];
+      q1.x = zs[(jz * 16 + r0 + 4) * 64 + lane]; q1.y = zs[(jz * 16 + r0 + 5) * 64 + lane];
+      q1.z = zs[(jz * 16 + r0 + 6) * 64 + lane]; q1.w = zs[(jz * 16 + r0 + 7) * 64 + lane];
+      h8 bh, bl;
+      split8(q0, q1, bh, bl);
+      sacc = mfma16(wr[ks][1], bh, sacc);
+      sacc = mfma16(wr[ks][0], bl, sacc);
+      sacc = mfma16(wr[ks][0], bh, sacc);
+    }
+    if (!last) {
+      if (rok) {
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(sg_of(b + 1), 0, 65536, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) granule2_store(srs, (unsigned)(j * 64 + lane) * 128u + 16u * r, epoch, sacc[2 * r], sacc[2 * r + 1]);
+      }
+      RL_TS(4, 7);
+    } else {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n0 = 32 * j + 8 * rq + 4 * h;
+        const f32x4 bv = ldg4(a.ws + a.skip_bias_off + n0);
+        f32x4 v;
+        v.x = wn_act(sacc[4 * rq + 0] + bv.x, a.skip_act); v.y = wn_act(sacc[4 * rq + 1] + bv.y, a.skip_act);
+        v.z = wn_act(sacc[4 * rq + 2] + bv.z, a.skip_act); v.w = wn_act(sacc[4 * rq + 3] + bv.w, a.skip_act);
+        if (rok) {
+          wmax = wn_absmax_acc(wmax, v.x, v.y, v.z, v.w);
+          *reinterpret_cast<f32x4*>(a.ws + a.skiprow_off + (int64_t)row * 128 + n0) = v;
+        }
+      }
+    }
+  }
+  if (a.guard && (wave < 4 || (skip_on && last))) {
+    wmax = wn_wave_absmax_bits(wmax);
+    if (lane == 0) wn_absmax_publish_any(a.guard, wmax);
+  }
+}
+
+// floats of workspace the relay's granule areas take: [x | skip accumulator][block][tile][8192 granules]
+int64_t wn_gen_relay128_floats(int B, int nblocks) { return (int64_t)2 * nblocks * ((B + 31) / 32) * 8192 * 2; }
+
+// knob 24: phase stamps of the relay (profiling hook, read by wn_debug_relay_ts)
+static unsigned long long* g_relay_ts = nullptr;
+extern "C" int wn_debug_relay_ts(unsigned long long* out, int nblocks) {
+  if (!g_relay_ts || nblocks > 128) return -1;
+  return (int)hipMemcpy(out, g_relay_ts, (size_t)nblocks * 8 * 8, hipMemcpyDeviceToHost);
+}
+
+int wn_launch_gen_relay128(const WnGen128Args& a0, hipStream_t s) {
+  WnGen128Args a = a0;
+  a.ts = nullptr;
+  if (wn_debug_get(24) && a.nblocks <= 128) {
+    if (!g_relay_ts) { (void)hipMalloc((void**)&g_relay_ts, 128 * 8 * 8); (void)hipMemset(g_relay_ts, 0, 128 * 8 * 8); }
+    a.ts = g_relay_ts;
+  }
+  if (a.B <= 0 || a.nblocks <= 0) return WN_OK;
+  if (a.ntiles != (a.B + 31) / 32 || a.epoch == 0 || !a.tmo || a.relay_off < 0) { wn_set_error("gen_relay128: bad arguments"); return WN_E_INVALID; }
+  hipLaunchKernelGGL(wn_gen_relay128_kernel, dim3((unsigned)(a.ntiles * a.nblocks)), dim3(512), 0, s, a);
+  WN_HIP_CHECK(hipGetLastError());
+  return WN_OK;
+}
+
 int wn_launch_gen_chain128(const WnGen128Args& a, hipStream_t s) {
   if (a.B <= 0 || a.nblocks <= 0) return WN_OK;
   hipLaunchKernelGGL(wn_gen_chain128_kernel, dim3((unsigned)((a.B + 31) / 32)), dim3(512), 0, s, a);

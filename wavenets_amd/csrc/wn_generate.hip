@@ -34,6 +34,8 @@ struct GenLayout {
   int64_t prime;                       // priming forward workspace (make_layout(B, RF, inference))
   int64_t win0, win1, last, lastp, samp;
   int64_t guard;                       // range guard of the call: running max-abs of every input of a split-precision kernel
+                                       // (+ 1: the relay's give-up word, see wn_gen_relay128_kernel)
+  int64_t relay;                       // granule areas of the 128-channel relay, or < 0
   int64_t xin;                         // [KS][B]
   std::vector<int64_t> ring;           // per block [nslots][B][R]: inputs of the first dilated conv
   std::vector<int> nslots;
@@ -55,7 +57,8 @@ GenLayout gen_layout(const wn_plan* p, int B, bool queued) {
   G.last = cv.take((int64_t)B * p->Cout);
   G.lastp = cv.take((int64_t)B * p->Cout);
   G.samp = cv.take(B);
-  G.guard = cv.take(1);
+  G.guard = cv.take(2);
+  G.relay = -1;
   G.xin = G.Zrow = G.skiprow = G.hrow0 = G.hrow1 = G.dummy = G.u0 = 0;
   if (queued) {
     G.xin = cv.take((int64_t)p->KS * B);
@@ -77,6 +80,7 @@ GenLayout gen_layout(const wn_plan* p, int B, bool queued) {
     G.hrow1 = cv.take((int64_t)B * 2 * p->D);
     G.dummy = cv.take((int64_t)B * p->R);
     G.u0 = cv.take(wn_gen_u0_floats(B, p->N, p->D));
+    if (p->LPB == 1 && wn_gen_block128_supported(p->R, p->D, p->KS)) G.relay = cv.take(wn_gen_relay128_floats(B, p->N));
     for (size_t i = 0; i + 1 < p->finals.size(); ++i) G.HArow.push_back(cv.take((int64_t)B * p->finals[i].cout));
   }
   G.total = cv.pos;
@@ -137,7 +141,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   // here; the caller reads the float after the call and repeats it with the exact-fp32 kernels when it reached
   // wn_range_limit().  One slot per call: cleared here, only ever raised afterwards.
   float* const gguard = workspace + G.guard;
-  WN_HIP_CHECK(hipMemsetAsync(gguard, 0, sizeof(float), s));
+  WN_HIP_CHECK(hipMemsetAsync(gguard, 0, 2 * sizeof(float), s));   // (and the relay's give-up word behind it)
 
   if (!queued) {
     // ---- naive sliding window: one full forward over the window per sample (src/model.py:296-305) ----
@@ -198,6 +202,10 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
                         !p->blocks.empty() && p->blocks[0].f16nat >= 0 && p->blocks[0].conv1.frag16 >= 0 && wn_debug_get(1) != 1 && fits32;
   // (its folded skip contraction -- 128 columns -- rides in the same launch)
   const bool skip_in_chain128 = chain128 && gfold && p->c.use_skip && skipw == 128 && skip_img >= 0;
+  // ... as a relay over one workgroup per block (wn_gen_relay128_kernel) unless knob 2 asks for the single workgroup
+  const bool relay128 = chain128 && G.relay >= 0 && wn_debug_get(2) == 0;
+  if (relay128)   // every granule tag starts below the first epoch
+    WN_HIP_CHECK(hipMemsetAsync(workspace + G.relay, 0, (size_t)wn_gen_relay128_floats(B, p->N) * sizeof(float), s));
   if ((fused_step || chain128) && (!p->d_gen || p->gen_B != B || p->gen_chain128 != chain128)) {
     p->gen_chain128 = chain128;
     std::vector<WnGenBlock> tab(p->N);
@@ -282,7 +290,13 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
         ca.skip_w16_off = G.prime + L.frag + skip_img; ca.skip_bias_off = G.prime + L.bfold; ca.skiprow_off = G.skiprow;
         ca.skip_act = p->c.activation;
       }
-      rc = wn_launch_gen_chain128(ca, s);
+      if (relay128) {
+        ca.ntiles = (B + 31) / 32; ca.epoch = (uint32_t)step; ca.relay_off = G.relay;
+        ca.tmo = reinterpret_cast<unsigned*>(gguard + 1);
+        rc = wn_launch_gen_relay128(ca, s);
+      } else {
+        rc = wn_launch_gen_chain128(ca, s);
+      }
       if (rc) return rc;
     }
     for (int b = 0; b < p->N && !chain128; ++b) {

@@ -276,8 +276,14 @@ struct WnGen128Args {
   // input causal conv (kernel size 2, one input channel) inside the chain: raw sample ring [2][B], kernel (2, 1, R), bias;
   // or xin null: block 0's ring slot was written by an earlier launch
   const float* xin; const float* causal_w; const float* causal_b;
+  // relay form (wn_gen_relay128_kernel): utterance tiles, workspace offset of the granule areas, the step's epoch (>= 1),
+  // the word a reader that gave up waiting writes
+  int32_t ntiles; uint32_t epoch; int64_t relay_off; unsigned* tmo;
+  unsigned long long* ts;          // phase stamps (knob 24) or null
 };
 int wn_launch_gen_chain128(const WnGen128Args& a, hipStream_t s);
+int wn_launch_gen_relay128(const WnGen128Args& a, hipStream_t s);
+int64_t wn_gen_relay128_floats(int B, int nblocks);
 // queued generation: where a sampler also puts its sample (output rows [rows][length] at column step; network input slot)
 struct WnEmit { float* out; int length; int step; float* xin_slot; };
 // the head of a generation step in one launch (wn_gen.hip)

@@ -728,7 +728,11 @@ class WaveNet(torch.nn.Module):
     # split-precision kernels -> the whole call again on the exact-fp32 kernels (same seed: same draws)
     if length > 0 and L.wn_debug_value(1) != 1:
       slot = L.wn_generate_guard_slot(self._plan, batch_size, int(bool(use_queues)))
-      if not (float(ws[slot]) < L.wn_range_limit()):
+      guard, watchdog = ws[slot:slot + 2].cpu()
+      if int(watchdog.view(torch.int32)) != 0:
+        raise RuntimeError(f'wn_generate: a workgroup of the generation relay gave up waiting for its predecessor '
+                           f'(code {int(watchdog.view(torch.int32))}); the samples of this call are invalid')
+      if not (float(guard) < L.wn_range_limit()):
         self.generation_guard_trips += 1
         with self.exact_fp32():
           run()
