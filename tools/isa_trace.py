@@ -3,7 +3,7 @@ wN = s_waitcnt vmcnt(N), B = s_barrier -- shows at a glance whether hipcc kept a
 them next to it with vmcnt(0) behind each (found that way in round 4: the fused forward block kernel's conv walked six
 exposed global round trips per tile).   usage: python tools/isa_trace.py file.hip kernel_substring [max_chars]"""
 import re, subprocess, sys, tempfile, os
-src, pat = sys.argv[1], sys.argv[2]
+src, pat = os.path.abspath(sys.argv[1]), sys.argv[2]
 lim = int(sys.argv[3]) if len(sys.argv) > 3 else 2400
 out = tempfile.mktemp(suffix='.s')
 subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=on', '-S', '--cuda-device-only', '-o', out, src],

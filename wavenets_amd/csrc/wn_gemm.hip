@@ -181,6 +181,39 @@ __global__ __launch_bounds__(256, (JT >= 8 ? 2 : (JT >= 4 ? 3 : 4))) void wn_gem
         }
       });
     };
+    constexpr int PF = 8;
+    if (JT == 1 && svec && splk == 0 && (sK & 7) == 0 && (nq % PF) == 0 && jb < a.JTtot) {   // wave-uniform
+      // One row tile per wave: 4 dependent products a k-quad (256 clocks) hide nothing of a load's latency, and with a
+      // few rows per launch (the last head layer of a queued generation step: 8 rows, K = 256, N = 30) there is no other
+      // wave to hide it either.  The general pipeline below guards its loads (row validity, ragged K, image rows), and
+      // hipcc drains vmcnt to 0 where such a guarded region ends: every k-quad then pays a whole round trip (17 us for
+      // 32 quads).  This form has NO guarded load -- rows are clamped and zeroed by a select, the refill past the end
+      // re-reads the last quad -- and a ring of PF register sets keeps PF - 1 quads in flight (17 -> 6 us).  Same
+      // products in the same order.
+      const f32x4* xp = reinterpret_cast<const f32x4*>(xrow + 4 * h);
+      const f32x4* ap = fr;
+      const int64_t astep = (int64_t)a.JTtot * 64;
+      f32x4 xr[PF], ar[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) { xr[i] = xp[2 * i]; ar[i] = ap[i * astep]; }
+      __builtin_amdgcn_sched_barrier(0);               // (or hipcc sinks every load next to its use, vmcnt(0) behind it)
+      for (int q0 = 0; q0 < nq; q0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          f32x4 xv = xr[i];
+          if (!valid) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 av = ar[i];
+          acc[0] = wn_mfma(av.x, xv.x, acc[0]);
+          acc[0] = wn_mfma(av.y, xv.y, acc[0]);
+          acc[0] = wn_mfma(av.z, xv.z, acc[0]);
+          acc[0] = wn_mfma(av.w, xv.w, acc[0]);
+          const int qn = min(q0 + i + PF, nq - 1);
+          xr[i] = xp[2 * qn];
+          ar[i] = ap[qn * astep];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     // software pipeline, one k-quad ahead, two named register sets (no copies)
     f32x4 x0, x1, a0[JT], a1[JT];
     x0 = load_x(0);
@@ -197,6 +230,7 @@ __global__ __launch_bounds__(256, (JT >= 8 ? 2 : (JT >= 4 ? 3 : 4))) void wn_gem
       compute(x1, a1);
     }
     if (q < nq) compute(x0, a0);
+    }
   }
 
   if (t >= a.T) return;

@@ -439,12 +439,51 @@ __device__ __forceinline__ void relay_give_up(unsigned* tmo, int code, int lane)
 
 __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a) {
   constexpr int R = 128, D = 128, NK1 = 16, NK2 = 8;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NK1 * 2048 + 2 * 4 * 16 * 64 * 4];
-  f32x4* xs = reinterpret_cast<f32x4*>(smem);
-  float* gs = reinterpret_cast<float*>(smem + NK1 * 2048);
-  float* zs = gs + 4 * 16 * 64;
+  // LDS: B operands of the conv, ALREADY split into fp16 hi | lo, [16 k-steps][hi, lo][64 lanes] x 16 B -- the split is done
+  // once by the thread that stages a piece, not by each of the eight waves in front of every product (the operand
+  // conversions sat between the LDS read and the products of every k-step of the critical path) | the newest tap in fp32
+  // (the residual) [1024 pieces] | gate tiles [4][4 quads][64] | z operands, split the same way, [8 k-steps][hi, lo][64]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NK1 * 2048 + 1024 * 16 + 4 * 4 * 64 * 16 + NK2 * 2048];
+  __shared__ unsigned x_sent;                          // waves 0..3 that have issued their hand-over stores
+  h8* const xh = reinterpret_cast<h8*>(smem);
+  f32x4* const xr = reinterpret_cast<f32x4*>(smem + NK1 * 2048);
+  f32x4* const gs4 = reinterpret_cast<f32x4*>(smem + NK1 * 2048 + 1024 * 16);
+  h8* const zh = reinterpret_cast<h8*>(smem + NK1 * 2048 + 1024 * 16 + 4 * 4 * 64 * 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl = lane & 31, h = lane >> 5;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  // quad q (0, 1) of k-step ks of lane l: the split8 of wn_stream.h on one half of the operand
+  auto put_quad = [&](h8* base, int ks, int q, int l, const f32x4& v) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const _Float16 hh = (_Float16)f[e];
+      hi[e] = hh;
+      lo[e] = (_Float16)(f[e] - (float)hh);
+    }
+    h4* b4 = reinterpret_cast<h4*>(base);
+    b4[((ks * 2 + 0) * 64 + l) * 2 + q] = hi;
+    b4[((ks * 2 + 1) * 64 + l) * 2 + q] = lo;
+  };
+  // acc += W^T b over k-steps K0 .. K0 + NK - 1: operands of k-step k + 1 are read before the products of k-step k issue
+  auto mac = [&](f32x16& acc, auto w_of, const h8* bop, auto k0_, auto nk_) {
+    constexpr int K0 = decltype(k0_)::value, NK = decltype(nk_)::value;
+    h8 bh[2], bl[2];
+    bh[0] = bop[(K0 * 2 + 0) * 64 + lane];
+    bl[0] = bop[(K0 * 2 + 1) * 64 + lane];
+    wn_static_for<NK>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      if constexpr (ks + 1 < NK) {
+        bh[(ks + 1) & 1] = bop[((K0 + ks + 1) * 2 + 0) * 64 + lane];
+        bl[(ks + 1) & 1] = bop[((K0 + ks + 1) * 2 + 1) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc = mfma16(w_of(K0 + ks, 1), bh[ks & 1], acc);
+      acc = mfma16(w_of(K0 + ks, 0), bl[ks & 1], acc);
+      acc = mfma16(w_of(K0 + ks, 0), bh[ks & 1], acc);
+    });
+  };
   const int b = (int)blockIdx.x / a.ntiles, tile = (int)blockIdx.x % a.ntiles;   // block-major: predecessors first
   const int row = tile * 32 + tl;
   const bool rok = row < a.B;
@@ -452,10 +491,11 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
   const bool skip_on = a.skip_w16_off >= 0;
   const bool last = b + 1 == a.nblocks;
   float wmax = 0.f;
-  // knob 24: s_memtime stamps of tile 0, [block][8]: 0 entry, 1 older tap staged, 2 older tap's products done, 3 input arrived,
+  // knob 24: s_memtime stamps of tile 0, [block][8]: 0 entry, 1 older tap staged, 2 older tap's products done, 3 input arrived (every wave's pieces in LDS),
   // 4 z ready, 5 output handed on (wave 0); 6 skip accumulator arrived, 7 handed on (wave 4)
 #define RL_TS(w, k) do { if (a.ts && tile == 0 && tid == 64 * (w)) a.ts[b * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   RL_TS(0, 0);
+  if (tid == 0) x_sent = 0;                            // (visible after the first barrier; first read far behind it)
   const WnGenBlock g = a.blocks[b];
   // granule areas of this workgroup's INPUT (written by block b - 1) and OUTPUT (read by block b + 1)
   unsigned long long* const gbase = reinterpret_cast<unsigned long long*>(a.ws + a.relay_off);
@@ -509,7 +549,8 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
       v = ldg4(src);
     }
     if (r2 >= a.B) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    xs[e] = v;
+    put_quad(xh, c, q, l, v);
+    if (c >= 8) xr[e - 1024] = v;
   }
   f32x16 u;
 #pragma unroll
@@ -538,15 +579,8 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
   __syncthreads();
   RL_TS(0, 1);
   // ---- gated conv, older tap: k-steps 0..7 ----
-#pragma unroll
-  for (int c = 0; c < NK1 / 2; ++c) {
-    const f32x4 q0 = xs[(c * 2 + 0) * 64 + lane], q1 = xs[(c * 2 + 1) * 64 + lane];
-    h8 bh, bl;
-    split8(q0, q1, bh, bl);
-    u = mfma16(wd[c][1], bh, u);
-    u = mfma16(wd[c][0], bl, u);
-    u = mfma16(wd[c][0], bh, u);
-  }
+  auto wd_of = [&](int c, int hl) -> const h8& { return wd[c][hl]; };
+  mac(u, wd_of, xh, std::integral_constant<int, 0>{}, std::integral_constant<int, NK1 / 2>{});
   RL_TS(0, 2);
   // ---- the block input of this step, from block b - 1: pieces 1024..2047 (2 per thread, 4 granules each) ----
   if (b > 0) {
@@ -581,25 +615,38 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
       if (++spins > WN_RELAY_SPINS) { relay_give_up(a.tmo, 1000 + b, lane); break; }
       __builtin_amdgcn_s_sleep(1);
     }
-    RL_TS(0, 3);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) xs[1024 + tid + 512 * i] = v[i];
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 512 * i;                       // piece 1024 + e: k-step 8 + (e >> 7), quad (e >> 6) & 1, lane e & 63
+      put_quad(xh, 8 + (e >> 7), (e >> 6) & 1, e & 63, v[i]);
+      xr[e] = v[i];
+    }
     __syncthreads();
+    RL_TS(0, 3);
   }
   // ---- gated conv, newest tap: k-steps 8..15 ----
-#pragma unroll
-  for (int c = NK1 / 2; c < NK1; ++c) {
-    const f32x4 q0 = xs[(c * 2 + 0) * 64 + lane], q1 = xs[(c * 2 + 1) * 64 + lane];
-    h8 bh, bl;
-    split8(q0, q1, bh, bl);
-    u = mfma16(wd[c][1], bh, u);
-    u = mfma16(wd[c][0], bl, u);
-    u = mfma16(wd[c][0], bh, u);
-  }
+  mac(u, wd_of, xh, std::integral_constant<int, NK1 / 2>{}, std::integral_constant<int, NK1 / 2>{});
   // the gate: waves 4..7 turn their tile into sigmoids while waves 0..3 turn theirs into tanh's, then one exchange
+  // The skip accumulator of block b - 1 was handed over BEFORE that block's rows (its products run while the 1x1 of the
+  // rows is still busy), so it has landed by now: waves 4..7 request it here, under their sigmoids, and check the tags
+  // after the z exchange.  Kept out of the phase in which waves 0..3 issue their hand-over stores: those are the chain's
+  // critical path, they share the CU's one memory queue with every other request of the workgroup, and a wave that
+  // polls 8 x 16 B per lane there was measured to stretch "z ready -> rows handed on" from 1.8 to 2.9 us.
+  const bool skip_recv = skip_on && wave >= 4 && b > 0 && rok;
+  const int sj = wave - 4;
+  u32x4 sq[8];
+  if (skip_recv) {
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(sg_of(b), 0, 65536, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sq[r] = granule2_load(srs, (unsigned)(sj * 64 + lane) * 128u + 16u * r);
+  }
+  // (both exchanges go through LDS as the lanes' own 16-byte quads: a D-layout quad of tile j IS the B-operand piece of the
+  // same lane for k-steps 2 j, 2 j + 1 of the next contraction -- 4 LDS instructions a tile instead of 16)
   if (wave >= 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gs[((wave - 4) * 16 + r) * 64 + lane] = wn_sigmoid_fast(u[r]);
+    for (int rq = 0; rq < 4; ++rq)
+      gs4[((wave - 4) * 4 + rq) * 64 + lane] = f32x4{wn_sigmoid_fast(u[4 * rq + 0]), wn_sigmoid_fast(u[4 * rq + 1]),
+                                                     wn_sigmoid_fast(u[4 * rq + 2]), wn_sigmoid_fast(u[4 * rq + 3])};
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) u[r] = wn_tanh_fast(u[r]);
@@ -608,10 +655,11 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
   f32x4 bv4[4];
   if (wave < 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float sg = gs[(wave * 16 + r) * 64 + lane];
-      u[r] = u[r] * sg;
-      zs[(wave * 16 + r) * 64 + lane] = u[r];
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 sg = gs4[(wave * 4 + rq) * 64 + lane];
+      u[4 * rq + 0] = u[4 * rq + 0] * sg.x; u[4 * rq + 1] = u[4 * rq + 1] * sg.y;
+      u[4 * rq + 2] = u[4 * rq + 2] * sg.z; u[4 * rq + 3] = u[4 * rq + 3] * sg.w;
+      put_quad(zh, 2 * wave + (rq >> 1), rq & 1, lane, f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]});
     }
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) bv4[rq] = ldg4(a.params + g.bias_r_off + 32 * wave + 8 * rq + 4 * h);
@@ -625,20 +673,8 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
       const f32x4 bv = bv4[rq];
       o[4 * rq + 0] = bv.x; o[4 * rq + 1] = bv.y; o[4 * rq + 2] = bv.z; o[4 * rq + 3] = bv.w;
     }
-#pragma unroll
-    for (int ks = 0; ks < NK2; ++ks) {
-      const int jz = ks >> 1, r0 = 8 * (ks & 1);
-      f32x4 q0, q1;
-      q0.x = zs[(jz * 16 + r0 + 0) * 64 + lane]; q0.y = zs[(jz * 16 + r0 + 1) * 64 + lane];
-      q0.z = zs[(jz * 16 + r0 + 2) * 64 + lane]; q0.w = zs[(jz * 16 + r0 + 3) * 64 + lane];
-      q1.x = zs[(jz * 16 + r0 + 4) * 64 + lane]; q1.y = zs[(jz * 16 + r0 + 5) * 64 + lane];
-      q1.z = zs[(jz * 16 + r0 + 6) * 64 + lane]; q1.w = zs[(jz * 16 + r0 + 7) * 64 + lane];
-      h8 bh, bl;
-      split8(q0, q1, bh, bl);
-      o = mfma16(wr[ks][1], bh, o);
-      o = mfma16(wr[ks][0], bl, o);
-      o = mfma16(wr[ks][0], bh, o);
-    }
+    auto wr_of = [&](int ks, int hl) -> const h8& { return wr[ks][hl]; };
+    mac(o, wr_of, zh, std::integral_constant<int, 0>{}, std::integral_constant<int, NK2>{});
     // residual = this lane's own pieces of the newest tap; the sum goes to block b + 1 as granules FIRST (its workgroup
     // is waiting for them), then to that block's ring slot of this time step (read by later launches only)
     unsigned long long* xgn = last ? nullptr : xg_of(b + 1);
@@ -657,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
       const int piece = ((8 + 2 * wave + (rq >> 1)) * 2 + (rq & 1)) * 64 + lane;
       if (rok) wmax = wn_absmax_acc(wmax, ov[rq].x, ov[rq].y, ov[rq].z, ov[rq].w);
       if (a.residual) {
-        const f32x4 rv = xs[piece];
+        const f32x4 rv = xr[piece - 1024];
         if (rok) wmax = wn_absmax_acc(wmax, rv.x, rv.y, rv.z, rv.w);
         ov[rq].x += rv.x; ov[rq].y += rv.y; ov[rq].z += rv.z; ov[rq].w += rv.w;
       }
@@ -666,6 +702,7 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
         granule2_store(xnrs, (unsigned)(piece - 1024) * 32u + 16u, epoch, ov[rq].z, ov[rq].w);
       }
     }
+    if (lane == 0) __hip_atomic_fetch_add(&x_sent, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     RL_TS(0, 5);
     if (dst && rok) {
 #pragma unroll
@@ -688,41 +725,31 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    if (b > 0 && rok) {
+    if (skip_recv) {
       const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(sg_of(b), 0, 65536, 0x00020000);
       const unsigned soff = (unsigned)(j * 64 + lane) * 128u;
       for (unsigned spins = 0;;) {
         bool ok = true;
-        u32x4 q[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) q[r] = granule2_load(srs, soff + 16u * r);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          ok = ok && q[r].y == epoch && q[r].w == epoch;
-          sacc[2 * r] = __uint_as_float(q[r].x);
-          sacc[2 * r + 1] = __uint_as_float(q[r].z);
+          ok = ok && sq[r].y == epoch && sq[r].w == epoch;
+          sacc[2 * r] = __uint_as_float(sq[r].x);
+          sacc[2 * r + 1] = __uint_as_float(sq[r].z);
         }
         if (ok) break;                                  // (per lane: the lanes of a wave leave the loop one by one)
         if (++spins > WN_RELAY_SPINS) { relay_give_up(a.tmo, 2000 + b, 0); break; }
         __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sq[r] = granule2_load(srs, soff + 16u * r);
       }
     }
     RL_TS(4, 6);
-#pragma unroll
-    for (int ks = 0; ks < NK2; ++ks) {
-      const int jz = ks >> 1, r0 = 8 * (ks & 1);
-      f32x4 q0, q1;
-      q0.x = zs[(jz * 16 + r0 + 0) * 64 + lane]; q0.y = zs[(jz * 16 + r0 + 1) * 64 + lane];
-      q0.z = zs[(jz * 16 + r0 + 2) * 64 + lane]; q0.w = zs[(jz * 16 + r0 + 3) * 64 + lane];
-      q1.x = zs[(jz * 16 + r0 + 4) * 64 + lane]; q1.y = zs[(jz * 16 + r0 + 5) * 64 + lane];
-      q1.z = zs[(jz * 16 + r0 + 6) * 64 + lane]; q1.w = zs[(jz * 16 + r0 + 7) * 64 + lane];
-      h8 bh, bl;
-      split8(q0, q1, bh, bl);
-      sacc = mfma16(wr[ks][1], bh, sacc);
-      sacc = mfma16(wr[ks][0], bl, sacc);
-      sacc = mfma16(wr[ks][0], bh, sacc);
-    }
+    auto wr_of = [&](int ks, int hl) -> const h8& { return wr[ks][hl]; };
+    mac(sacc, wr_of, zh, std::integral_constant<int, 0>{}, std::integral_constant<int, NK2>{});
     if (!last) {
+      // (behind the rows' hand-over stores, see above; bounded like every wait of this kernel)
+      for (unsigned spins = 0; __hip_atomic_load(&x_sent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u && spins < WN_RELAY_SPINS; ++spins)
+        __builtin_amdgcn_s_sleep(1);
       if (rok) {
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(sg_of(b + 1), 0, 65536, 0x00020000);
 #pragma unroll
