@@ -118,17 +118,24 @@ def generation_leg(dev, B: int = 8, n: int = 1000):
   # configs[3] weights (128 residual channels, mixture-of-logistics draws): the queued sampler's other kernel family
   m3 = WaveNet(**OTHER_CONFIGS['configs[3]'][0], device=dev, seed=0)
   w3 = (torch.rand(B, m3.receptive_field, 1, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
-  ts = []
-  for k in (100, 400):
-    m3.generate(k, sample=w3, use_queues=True, deterministic=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m3.generate(k, sample=w3, use_queues=True, deterministic=False)
-    torch.cuda.synchronize()
-    ts.append(time.perf_counter() - t0)
-  per = (ts[1] - ts[0]) / 300
-  res['configs3_queued_stochastic'] = {'ms_per_sample_step': per * 1e3, 'samples_per_s_per_utterance': 1.0 / per,
-                                       'samples_per_s_aggregate': B / per}
+  from wavenets_amd import _lib
+  # (the default: one workgroup per block, rows handed from CU to CU inside the launch -- wn_gen_relay128_kernel; knob 2:
+  # every block inside one workgroup per utterance tile -- wn_gen_chain128_kernel, the form of the earlier rounds)
+  for name, knob in (('configs3_queued_stochastic', 0), ('configs3_queued_stochastic_one_workgroup', 1)):
+    _lib.lib().wn_debug_set(2, knob)
+    try:
+      ts = []
+      for k in (100, 400):
+        m3.generate(k, sample=w3, use_queues=True, deterministic=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m3.generate(k, sample=w3, use_queues=True, deterministic=False)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    finally:
+      _lib.lib().wn_debug_set(2, 0)
+    per = (ts[1] - ts[0]) / 300
+    res[name] = {'ms_per_sample_step': per * 1e3, 'samples_per_s_per_utterance': 1.0 / per, 'samples_per_s_aggregate': B / per}
   return res
 
 

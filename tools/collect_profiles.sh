@@ -1,6 +1,6 @@
 #!/bin/bash
 # All rocprofv3 runs behind profiles/<tag>_*: run on the GPU box from the repo root (gpurun -- 'bash tools/collect_profiles.sh').
-#   kernel trace of `python bench.py` (configs[1] headline), and for configs[1] (tools/prof_train.py) and configs[3]
+#   kernel trace of `python bench.py` (configs[1] headline) and of queued generation at configs[3] (tools/prof_gen128.py), and for configs[1] (tools/prof_train.py) and configs[3]
 #   (tools/prof_cfg4.py): kernel trace + SEPARATE --pmc passes for FETCH_SIZE, WRITE_SIZE and the SQ counters
 #   (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no --pmc together with trace domains other than
 #   --kernel-trace).  Outputs under gpurun_out/prof_<tag>/; tools/summarise_profiles.py turns them into
@@ -24,6 +24,7 @@ for cfg in train cfg4; do
   run ${cfg}_w --kernel-trace --pmc WRITE_SIZE -d $OUT/${cfg}_w -o $cfg -- python3 $prog > $OUT/${cfg}_w.log 2>&1
   run ${cfg}_sq --kernel-trace --pmc $SQ -d $OUT/${cfg}_sq -o $cfg -- python3 $prog > $OUT/${cfg}_sq.log 2>&1
 done
+run gen128_ks --kernel-trace --stats -d $OUT/gen128_ks -o gen128 -- python3 $ROOT/tools/prof_gen128.py > $OUT/gen128_ks.log 2>&1
 # summaries only travel back (the raw databases and counter tables are tens of MB)
 # (the raw outputs are deleted only after the summariser succeeded: a failed summary must not cost a second profiling run)
 python3 $ROOT/tools/summarise_profiles.py $TAG $ROOT/gpurun_out/prof_${TAG}_summary > $OUT/../prof_${TAG}_summary.log 2>&1 \

@@ -1,6 +1,7 @@
 """profiles/<tag>_*.csv from the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_<tag>/):
    <tag>_bench_kernel_stats.csv                    kernel trace of `python bench.py` (configs[1])
    <tag>_{train,cfg4}_kernel_stats.csv             per-kernel summary of the profiling drivers (4 training steps each)
+   <tag>_gen128_kernel_stats.csv                   queued generation on the configs[3] network (tools/prof_gen128.py: 300 samples, batch 8)
    <tag>_{train,cfg4}_pmc_hbm_traffic.csv          FETCH_SIZE x 2 (gfx950: wide coalesced reads report half) + WRITE_SIZE, per launch
    <tag>_{train,cfg4}_pmc_sq.csv                   SQ counters per launch and three derived columns:
        wait_any_frac   = SQ_WAIT_ANY / SQ_WAVE_CYCLES (both in quad-cycles, summed over waves): share of wave lifetime parked
@@ -31,7 +32,7 @@ def agg(path, names):
   return a
 
 
-for name, dst in (('bench_ks', 'bench'), ('train_ks', 'train'), ('cfg4_ks', 'cfg4')):
+for name, dst in (('bench_ks', 'bench'), ('train_ks', 'train'), ('cfg4_ks', 'cfg4'), ('gen128_ks', 'gen128')):
   f = find(name, '*kernel_stats.csv')
   if f:
     shutil.copy(f, os.path.join(dest, f'{tag}_{dst}_kernel_stats.csv'))
