@@ -128,18 +128,19 @@ __global__ __launch_bounds__(512, 2) void wn_bwd_pair_kernel(WnBwdPairArgs a) {
   };
 
   float wmax_x = 0.f, wmax_u = 0.f;
-  const int64_t tstride = (int64_t)gridDim.x * 8;
-  int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  const WnTileWalk walk = wn_tile_walk(ntiles, 8, wave);          // each XCD a contiguous eighth of the tiles (wn_common.h)
+  const int64_t tstride = walk.stride, tend = walk.end;
+  int64_t tile = walk.first;
   TileCtx cur, nxt;
   f32x4 xr[BP_PF][2];
   bool okr[BP_PF];
-  if (tile < ntiles) {
+  if (tile < tend) {
     make_ctx(tile, cur);
 #pragma unroll
     for (int k = 0; k < BP_PF; ++k) load_x(cur, k, xr[k][0], xr[k][1], okr[k]);
   }
-  for (; tile < ntiles; tile += tstride) {
-    const bool has_next = tile + tstride < ntiles;                 // wave-uniform
+  for (; tile < tend; tile += tstride) {
+    const bool has_next = tile + tstride < tend;                   // wave-uniform
     if (has_next) make_ctx(tile + tstride, nxt);
     const bool tin = cur.t < a.T;
     const int64_t row = cur.row0 + (tin ? tl : 0);                  // rows past the end read the tile's first row (unused)

@@ -191,3 +191,25 @@ __device__ __forceinline__ void wn_guard_publish_over(float* slot, float wmax) {
 
 void wn_set_error(const char* fmt, ...);
 int wn_debug_get(int key);   // per-thread switches (wn_error.cpp): 1 = exact-fp32 kernels, 9 = no side stream, 24 / 29 = profiling hooks
+
+// XCD-aware walk over the 32-row tiles of a launch.  Workgroups are dealt to the 8 XCDs round-robin by index and every
+// XCD has an L2 of its own: with tile = workgroup * waves + wave, a tile's older tap (rows t - d of the same utterance,
+// d / 32 tiles back) was fetched through ANOTHER XCD's L2 for every dilation >= 32 and comes from the memory side a second
+// time.  Here each XCD takes one contiguous eighth of the tiles, so the rows a tile shares with its neighbours in time
+// were requested by a CU behind the same L2.  (Results do not depend on the order of the tiles.)
+struct WnTileWalk { int64_t first, end, stride; };
+__device__ __forceinline__ WnTileWalk wn_tile_walk(int64_t ntiles, int waves, int wave) {
+  WnTileWalk w;
+  if ((gridDim.x & 7u) == 0u) {
+    const int64_t n8 = (ntiles + 7) >> 3;
+    const int64_t x = blockIdx.x & 7u;
+    w.first = x * n8 + (int64_t)(blockIdx.x >> 3) * waves + wave;
+    w.end = (x + 1) * n8 < ntiles ? (x + 1) * n8 : ntiles;
+    w.stride = (int64_t)(gridDim.x >> 3) * waves;
+  } else {
+    w.first = (int64_t)blockIdx.x * waves + wave;
+    w.end = ntiles;
+    w.stride = (int64_t)gridDim.x * waves;
+  }
+  return w;
+}

@@ -203,7 +203,15 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   // (its folded skip contraction -- 128 columns -- rides in the same launch)
   const bool skip_in_chain128 = chain128 && gfold && p->c.use_skip && skipw == 128 && skip_img >= 0;
   // ... as a relay over one workgroup per block (wn_gen_relay128_kernel) unless knob 2 asks for the single workgroup
-  const bool relay128 = chain128 && G.relay >= 0 && wn_debug_get(2) == 0;
+  // (only while every workgroup of a step can be resident at once -- one per CU: a workgroup waits for its predecessor
+  // inside the launch; with more workgroups than CUs the chain would still drain as long as they start in index order,
+  // which HIP does not promise)
+  static int cu_count = 0;
+  if (cu_count == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu_count = -1;
+  }
+  const bool relay128 = chain128 && G.relay >= 0 && wn_debug_get(2) == 0 && (int64_t)((B + 31) / 32) * p->N <= cu_count;
   if (relay128)   // every granule tag starts below the first epoch
     WN_HIP_CHECK(hipMemsetAsync(workspace + G.relay, 0, (size_t)wn_gen_relay128_floats(B, p->N) * sizeof(float), s));
   if ((fused_step || chain128) && (!p->d_gen || p->gen_B != B || p->gen_chain128 != chain128)) {

@@ -119,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
   const int tiles_per_b = (a.T + 31) >> 5;
   const int64_t ntiles = (int64_t)a.B * tiles_per_b;
   float wmax = 0.f;                                      // forward range guard: max |x_out| of this wave's tiles
-  for (int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * G::WAVES) {
+  const WnTileWalk walk = wn_tile_walk(ntiles, G::WAVES, wave);
+  for (int64_t tile = walk.first; tile < walk.end; tile += walk.stride) {
     const int b = (int)(tile / tiles_per_b);
     const int t0 = (int)(tile % tiles_per_b) * 32;
     const int t = t0 + tl;
