@@ -442,13 +442,12 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
   // LDS: B operands of the conv, ALREADY split into fp16 hi | lo, [16 k-steps][hi, lo][64 lanes] x 16 B -- the split is done
   // once by the thread that stages a piece, not by each of the eight waves in front of every product (the operand
   // conversions sat between the LDS read and the products of every k-step of the critical path) | the newest tap in fp32
-  // (the residual) [1024 pieces] | gate tiles [4][4 quads][64] | z operands, split the same way, [8 k-steps][hi, lo][64]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NK1 * 2048 + 1024 * 16 + 4 * 4 * 64 * 16 + NK2 * 2048];
+  // (the residual) [1024 pieces] | z operands, split the same way, [8 k-steps][hi, lo][64]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NK1 * 2048 + 1024 * 16 + NK2 * 2048];
   __shared__ unsigned x_sent;                          // waves 0..3 that have issued their hand-over stores
   h8* const xh = reinterpret_cast<h8*>(smem);
   f32x4* const xr = reinterpret_cast<f32x4*>(smem + NK1 * 2048);
-  f32x4* const gs4 = reinterpret_cast<f32x4*>(smem + NK1 * 2048 + 1024 * 16);
-  h8* const zh = reinterpret_cast<h8*>(smem + NK1 * 2048 + 1024 * 16 + 4 * 4 * 64 * 16);
+  h8* const zh = reinterpret_cast<h8*>(smem + NK1 * 2048 + 1024 * 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl = lane & 31, h = lane >> 5;
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -508,7 +507,14 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
   const float* xnew = ring + (int64_t)(a.tau % g.nslots) * a.B * R;
   h8 wd[NK1][2];
   {
-    const char* base = reinterpret_cast<const char*>(a.ws + g.w16d_off) + (int64_t)wave * 2048 + lane * 16;
+    // Wave w owns a MIXED row tile of the gated conv: rows 0..15 = filter channels 16 w .. 16 w + 15, rows 16..31 = the gate
+    // channels of the same 16 (the two 16-row halves of image tiles w / 2 and 4 + w / 2), as in wn_gen_chain3_kernel.  A
+    // lane's 16 accumulators are then 8 filter values and THEIR 8 gate values: the gate runs in registers, nothing is
+    // exchanged through LDS, and every wave ends up with one k-step of z.  Only the lanes' fetch addresses differ from
+    // a plain tile: every output element is the same dot product over the same operands in the same order.
+    const int src_tile = tl < 16 ? (wave >> 1) : 4 + (wave >> 1);
+    const int src_lane = 32 * h + 16 * (wave & 1) + (tl & 15);
+    const char* base = reinterpret_cast<const char*>(a.ws + g.w16d_off) + (int64_t)src_tile * 2048 + src_lane * 16;
 #pragma unroll
     for (int c = 0; c < NK1; ++c) {
       wd[c][0] = ldg_h8(base + c * 16384);
@@ -552,17 +558,19 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
     put_quad(xh, c, q, l, v);
     if (c >= 8) xr[e - 1024] = v;
   }
+  // accumulator quad rq of the mixed tile: channels 16 w + 8 rq + 4 h .. (rq = 0, 1: filter), D + 16 w + 8 (rq - 2) + 4 h .. (gate)
+  auto uch = [&](int rq) { return (rq < 2 ? 0 : D - 16) + 16 * wave + 8 * rq + 4 * h; };
   f32x16 u;
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
-    const f32x4 bv = ldg4(a.params + g.bias_d_off + 32 * wave + 8 * rq + 4 * h);
+    const f32x4 bv = ldg4(a.params + g.bias_d_off + uch(rq));
     u[4 * rq + 0] = bv.x; u[4 * rq + 1] = bv.y; u[4 * rq + 2] = bv.z; u[4 * rq + 3] = bv.w;
   }
   if (g.cb_off >= 0) {
-    const float* cbp = a.ws + g.cb_off + (int64_t)(rok ? row : 0) * 2 * D + 4 * h + 32 * wave;
+    const float* cbp = a.ws + g.cb_off + (int64_t)(rok ? row : 0) * 2 * D;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
-      const f32x4 cv = ldg4(cbp + 8 * rq);
+      const f32x4 cv = ldg4(cbp + uch(rq));
       u[4 * rq + 0] += cv.x; u[4 * rq + 1] += cv.y; u[4 * rq + 2] += cv.z; u[4 * rq + 3] += cv.w;
     }
   }
@@ -626,10 +634,9 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
   }
   // ---- gated conv, newest tap: k-steps 8..15 ----
   mac(u, wd_of, xh, std::integral_constant<int, NK1 / 2>{}, std::integral_constant<int, NK1 / 2>{});
-  // the gate: waves 4..7 turn their tile into sigmoids while waves 0..3 turn theirs into tanh's, then one exchange
   // The skip accumulator of block b - 1 was handed over BEFORE that block's rows (its products run while the 1x1 of the
-  // rows is still busy), so it has landed by now: waves 4..7 request it here, under their sigmoids, and check the tags
-  // after the z exchange.  Kept out of the phase in which waves 0..3 issue their hand-over stores: those are the chain's
+  // rows is still busy), so it has landed by now: waves 4..7 request it here, under the gate's transcendentals, and check the
+  // tags once z is in LDS.  Kept out of the phase in which waves 0..3 issue their hand-over stores: those are the chain's
   // critical path, they share the CU's one memory queue with every other request of the workgroup, and a wave that
   // polls 8 x 16 B per lane there was measured to stretch "z ready -> rows handed on" from 1.8 to 2.9 us.
   const bool skip_recv = skip_on && wave >= 4 && b > 0 && rok;
@@ -640,32 +647,31 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
 #pragma unroll
     for (int r = 0; r < 8; ++r) sq[r] = granule2_load(srs, (unsigned)(sj * 64 + lane) * 128u + 16u * r);
   }
-  // (both exchanges go through LDS as the lanes' own 16-byte quads: a D-layout quad of tile j IS the B-operand piece of the
-  // same lane for k-steps 2 j, 2 j + 1 of the next contraction -- 4 LDS instructions a tile instead of 16)
-  if (wave >= 4) {
+  // the gate, in registers: accumulators 0..7 are filter channels, 8..15 their gate channels; z = k-step `wave` of the
+  // 1x1 and the skip contraction, split into fp16 hi | lo on the way into LDS
+  f32x4 zq[2];
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
-      gs4[((wave - 4) * 4 + rq) * 64 + lane] = f32x4{wn_sigmoid_fast(u[4 * rq + 0]), wn_sigmoid_fast(u[4 * rq + 1]),
-                                                     wn_sigmoid_fast(u[4 * rq + 2]), wn_sigmoid_fast(u[4 * rq + 3])};
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) u[r] = wn_tanh_fast(u[r]);
+  for (int q = 0; q < 2; ++q) {
+    zq[q].x = wn_tanh_fast(u[4 * q + 0]) * wn_sigmoid_fast(u[8 + 4 * q + 0]);
+    zq[q].y = wn_tanh_fast(u[4 * q + 1]) * wn_sigmoid_fast(u[8 + 4 * q + 1]);
+    zq[q].z = wn_tanh_fast(u[4 * q + 2]) * wn_sigmoid_fast(u[8 + 4 * q + 2]);
+    zq[q].w = wn_tanh_fast(u[4 * q + 3]) * wn_sigmoid_fast(u[8 + 4 * q + 3]);
+    put_quad(zh, wave, q, lane, zq[q]);
   }
-  __syncthreads();
   f32x4 bv4[4];
   if (wave < 4) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const f32x4 sg = gs4[(wave * 4 + rq) * 64 + lane];
-      u[4 * rq + 0] = u[4 * rq + 0] * sg.x; u[4 * rq + 1] = u[4 * rq + 1] * sg.y;
-      u[4 * rq + 2] = u[4 * rq + 2] * sg.z; u[4 * rq + 3] = u[4 * rq + 3] * sg.w;
-      put_quad(zh, 2 * wave + (rq >> 1), rq & 1, lane, f32x4{u[4 * rq + 0], u[4 * rq + 1], u[4 * rq + 2], u[4 * rq + 3]});
-    }
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) bv4[rq] = ldg4(a.params + g.bias_r_off + 32 * wave + 8 * rq + 4 * h);
   }
   __syncthreads();
   RL_TS(0, 4);
+  auto store_zrow = [&]() {                              // gated activations of this block (later launches only)
+    if (rok) {
+      float* zp = a.ws + a.zrow_off + ((int64_t)b * a.B + row) * D + 16 * wave + 4 * h;
+      *reinterpret_cast<f32x4*>(zp) = zq[0];
+      *reinterpret_cast<f32x4*>(zp + 8) = zq[1];
+    }
+  };
   if (wave < 4) {
     f32x16 o;
 #pragma unroll
@@ -708,16 +714,9 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) *reinterpret_cast<f32x4*>(dst + (int64_t)row * R + 32 * wave + 8 * rq + 4 * h) = ov[rq];
     }
-    if (rok) {                                          // gated activations of this block (later launches only)
-      float* zp = a.ws + a.zrow_off + ((int64_t)b * a.B + row) * D + 32 * wave + 4 * h;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        f32x4 zv;
-        zv.x = u[4 * rq + 0]; zv.y = u[4 * rq + 1]; zv.z = u[4 * rq + 2]; zv.w = u[4 * rq + 3];
-        *reinterpret_cast<f32x4*>(zp + 8 * rq) = zv;
-      }
-    }
-  } else if (skip_on) {
+    store_zrow();
+  }
+  if (wave >= 4 && skip_on) {
     // ---- folded skip contraction: the accumulator of column tile wave - 4 arrives from block b - 1 (same lane, same
     //      register), takes this block's 24 products, and travels on (or, after the last block, through the epilogue of
     //      wn_gemm_planes16s_kernel) ----
@@ -771,6 +770,7 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
       }
     }
   }
+  if (wave >= 4) store_zrow();                          // (last: nothing of waves 4..7 may sit in the memory queue before the rows' hand-over)
   if (a.guard && (wave < 4 || (skip_on && last))) {
     wmax = wn_wave_absmax_bits(wmax);
     if (lane == 0) wn_absmax_publish_any(a.guard, wmax);
