@@ -1021,6 +1021,23 @@ def test_queued_generation_128_channel_chain(B, cond, finals, skip, form):
   assert torch.equal(queued, again)
 
 
+@pytest.mark.parametrize('det', [True, False])
+@pytest.mark.parametrize('channels,sampler,mix,finals', [(64, 'logistic', 10, [128, 256]), (32, 'gaussian', 8, [64, 64]),
+                                                         (128, 'logistic', 5, [128, 128])])
+def test_queued_generation_mixture_head_in_one_launch(channels, sampler, mix, finals, det):
+  """Mixture heads in queued generation: the split-precision hidden layers, the exact-fp32 output layer (3 x mixtures
+  columns, the rows of wn_gemm_rows_kernel<1>) and the mixture sampler in ONE launch (wn_gen_head_kernel with f32_K > 0,
+  tail 3 / 4) behind the 64-channel chain, the 32-channel chain and the 128-channel relay: the sliding window's samples,
+  bit for bit, for arg-max and for Philox draws (src/model.py:423-503)."""
+  kw = dict(blocks=6, channels=channels, skip_channels=256, dilation_bound=32, final_layers_channels=finals,
+            activation='leaky_relu', num_mixtures=mix, sampling_function=sampler, bits=16)
+  ocfg, params, model = make_pair(seed=23, bias_range=0.3, **kw)
+  w = O.synthetic_waveform(5, model.receptive_field, seed=6).to(dev())
+  naive = model.generate(30, sample=w, use_queues=False, deterministic=det)
+  queued = model.generate(30, sample=w, use_queues=True, deterministic=det)
+  assert torch.equal(naive, queued), (naive - queued).abs().max()
+
+
 def test_generation_relay_under_load_and_long_runs():
   """The relay's hand-offs with the GPU busy on another stream (a large copy kernel loop competing for the CUs and the
   fabric) and over many steps: 600 samples at 30 blocks of 128 channels, bit-identical to the one-workgroup form."""

@@ -603,11 +603,7 @@ __global__ __launch_bounds__(256) void wn_sample_det_cat_kernel(const float* pre
 __global__ void wn_sample_det_mix_kernel(const float* pred, int64_t rows, int M, float* out, WnEmit em) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
-  const float* p = pred + row * 3 * M;
-  int bi = 0;
-  float best = p[0];
-  for (int k = 1; k < M; ++k) if (p[k] > best) { best = p[k]; bi = k; }
-  const float v = fminf(fmaxf(p[M + bi], -1.0f), 1.0f);
+  const float v = wn_mix_det_row(pred + row * 3 * M, M);
   out[row] = v;
   wn_emit_sample(em, row, v);
 }
@@ -675,27 +671,7 @@ __global__ void wn_sample_rand_mix_kernel(const float* pred, int64_t rows, int M
                                           uint64_t offset, float* out, WnEmit em) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
-  const float* p = pred + row * 3 * M;
-  uint32_t r[4];
-  wn_philox((uint64_t)row, offset, seed, r);
-  float wm = -INFINITY;
-  for (int k = 0; k < M; ++k) wm = fmaxf(wm, p[k]);
-  float wz = 0.f;
-  for (int k = 0; k < M; ++k) wz += expf(p[k] - wm);
-  const float target = wn_u01(r[0]) * wz;
-  int sel = M - 1;
-  float run = 0.f;
-  for (int k = 0; k < M; ++k) { run += expf(p[k] - wm); if (run > target) { sel = k; break; } }
-  const float mu = p[M + sel], sc = expf(p[2 * M + sel]);
-  float v;
-  if (kind == 1) {                       // logistic: mu + s (ln z - ln(1-z))     src/model.py:463-483
-    const float zz = wn_u01(r[1]);
-    v = mu + sc * (logf(zz) - logf(1.0f - zz));
-  } else {                               // gaussian: mu + s n                   src/model.py:423-443
-    const float u1 = wn_u01(r[1]), u2 = wn_u01(r[2]);
-    v = mu + sc * sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-  }
-  const float vc = fminf(fmaxf(v, -1.0f), 1.0f);
+  const float vc = wn_mix_rand_row(pred + row * 3 * M, M, kind, row, seed, offset);
   out[row] = vc;
   wn_emit_sample(em, row, vc);
 }

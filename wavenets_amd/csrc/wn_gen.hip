@@ -649,7 +649,8 @@ __device__ __forceinline__ void gn_head_body(const WnGenHeadArgs& a, int tile, u
     const int nks = a.K[li] / 16, nt = a.N[li] / 32;
     const unsigned char* ib = smem + (li & 1) * (16 * 2048);
     unsigned char* ob = smem + ((li + 1) & 1) * (16 * 2048);
-    const bool lastl = li + 1 == a.nlayers;
+    const bool to_f32 = li + 1 == a.nlayers && a.f32_K > 0;      // its output feeds the exact-fp32 last layer
+    const bool lastl = li + 1 == a.nlayers && !to_f32;
     if (wave < nt) {
       f32x16 acc;
 #pragma unroll
@@ -705,6 +706,14 @@ __device__ __forceinline__ void gn_head_body(const WnGenHeadArgs& a, int tile, u
           for (int rq = 0; rq < 4; ++rq) vm = wn_absmax_acc(vm, v[4 * rq + 0], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]);
           wn_guard_publish_over(a.guard, live ? vm : 0.f);
         }
+        if (to_f32) {
+          // ... or k-quads 4 wave .. 4 wave + 3 of the fp32 layer: accumulator quad rq of a lane IS that lane's B operand
+          // of quad 4 wave + rq (channels 8 q + 4 h .. + 3 of its row), kept in fp32
+          f32x4* xf = reinterpret_cast<f32x4*>(ob);
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            xf[(4 * wave + rq) * 64 + lane] = f32x4{v[4 * rq + 0], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
+        } else
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const f32x4 q0 = {v[8 * hf + 0], v[8 * hf + 1], v[8 * hf + 2], v[8 * hf + 3]};
@@ -719,11 +728,69 @@ __device__ __forceinline__ void gn_head_body(const WnGenHeadArgs& a, int tile, u
     }
     __syncthreads();
   }
+  // ---- exact-fp32 last layer (at most 32 columns: one row tile, one wave): wn_gemm_rows_kernel<1>'s arithmetic -- k-quads
+  // ascending, four v_mfma_f32_32x32x2_f32 a quad into one accumulator from zero, then + bias -- so the outputs are the
+  // per-layer launch's and the sliding window's.  Fragments eight quads ahead (a quad is 4 dependent products = 256 clocks).
+  if (a.f32_K > 0) {
+    float* lg = reinterpret_cast<float*>(smem + ((a.nlayers & 1) ^ 1) * (16 * 2048));   // [32 rows][32]: the buffer the last layer read
+    if (wave == 0) {
+      const f32x4* xf = reinterpret_cast<const f32x4*>(smem + (a.nlayers & 1) * (16 * 2048)) + lane;   // written by the last layer
+      const f32x4* fr = reinterpret_cast<const f32x4*>(a.ws + a.f32_w_off) + lane;    // [quad][64 lanes] (one row tile)
+      const int nq = a.f32_K / 8;
+      constexpr int PF = 8;
+      f32x4 ar[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) ar[i] = fr[(int64_t)min(i, nq - 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int q0 = 0; q0 < nq; q0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          f32x4 xv = xf[(q0 + i) * 64];
+          if (!live) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 av = ar[i];
+          acc = wn_mfma(av.x, xv.x, acc);
+          acc = wn_mfma(av.y, xv.y, acc);
+          acc = wn_mfma(av.z, xv.z, acc);
+          acc = wn_mfma(av.w, xv.w, acc);
+          ar[i] = fr[(int64_t)min(q0 + i + PF, nq - 1) * 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const float* bias = a.params + a.f32_bias_off;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = 8 * rq + 4 * h + e;
+          if (n < a.f32_N) {
+            const float w = acc[4 * rq + e] + bias[n];
+            lg[tl * 32 + n] = w;
+            if (live) a.ws[a.out_off + (int64_t)utt * a.f32_N + n] = w;
+          }
+        }
+    }
+    __syncthreads();
+    // mixture sampling tail and emit, one row per thread: the rows of wn_sample_det_mix_kernel / wn_sample_rand_mix_kernel
+    if (a.tail >= 3 && threadIdx.x < 32) {
+      const int row = tile * 32 + (int)threadIdx.x;
+      if (row < a.B) {
+        const float* p = lg + threadIdx.x * 32;
+        const float v = a.tail == 3 ? wn_mix_det_row(p, a.mix_M) : wn_mix_rand_row(p, a.mix_M, a.mix_kind, row, a.seed, a.offset);
+        if (a.samp) a.samp[row] = v;
+        a.em.out[(int64_t)row * a.em.length + a.em.step] = v;
+        if (a.em.xin_slot) a.em.xin_slot[row] = v;
+      }
+    }
+    return;
+  }
   // ---- categorical sampling tail (softmax -> arg max, or softmax -> inverse-CDF draw) and emit, one wave per row: the
   // rows of wn_gen_tail_cat_det_kernel / wn_sample_rand_cat_logits_kernel, so the samples are theirs.  The logits were
   // stored by other waves of this workgroup: the barrier above has drained those stores, and nothing has read these
   // lines into this CU's L1 before ----
-  if (a.tail != 0) {
+  if (a.tail == 1 || a.tail == 2) {
     const int C = a.N[a.nlayers - 1];
     float* q = reinterpret_cast<float*>(smem) + wave * 256;     // the operand buffers are free now (C <= 256)
     for (int i = wave; i < 32; i += 8) {
@@ -788,6 +855,12 @@ int wn_launch_gen_head(const WnGenHeadArgs& a, hipStream_t s) {
       wn_set_error("gen_head: unsupported layer shape");
       return WN_E_UNSUPPORTED;
     }
+  if (a.f32_K > 0 && (a.f32_K != a.N[a.nlayers - 1] || a.f32_K % 64 != 0 || a.f32_N < 1 || a.f32_N > 32 ||
+                      (a.tail >= 3 && 3 * a.mix_M != a.f32_N))) {
+    wn_set_error("gen_head: unsupported fp32 last layer");
+    return WN_E_UNSUPPORTED;
+  }
+  if (a.f32_K == 0 && a.tail >= 3) { wn_set_error("gen_head: the mixture tail follows the fp32 layer"); return WN_E_UNSUPPORTED; }
   hipLaunchKernelGGL(wn_gen_head_kernel, dim3((unsigned)((a.B + 31) / 32)), dim3(512), 0, s, a);
   WN_HIP_CHECK(hipGetLastError());
   return WN_OK;

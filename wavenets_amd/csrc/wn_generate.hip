@@ -247,6 +247,19 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     const ConvInfo& c = p->finals[i];
     head_fused = head_fused && c.frag16 >= 0 && c.cout % 32 == 0 && c.cout >= 64 && c.cout <= 256 && c.cin % 16 == 0 && c.cin <= 256;
   }
+  // mixture heads: the same launch with the exact-fp32 last layer (3 x mixtures columns: no split-precision image) and the
+  // mixture sampler behind the split-precision layers -- one launch instead of layers + 1 + sampler
+  bool head_mix = !head_fused && wn_debug_get(1) != 1 && p->c.head != WN_HEAD_CATEGORICAL && p->c.num_mixtures > 0 &&
+                  p->finals.size() >= first_final + 2 && (int)(p->finals.size() - first_final - 1) <= WN_GEN_HEAD_MAX &&
+                  hc0 % 16 == 0 && hc0 <= 256 && fits32;
+  if (head_mix) {
+    for (size_t i = first_final; i + 1 < p->finals.size(); ++i) {
+      const ConvInfo& c = p->finals[i];
+      head_mix = head_mix && c.frag16 >= 0 && c.cout % 32 == 0 && c.cout >= 64 && c.cout <= 256 && c.cin % 16 == 0 && c.cin <= 256;
+    }
+    const ConvInfo& cl = p->finals.back();
+    head_mix = head_mix && cl.cout == 3 * p->c.num_mixtures && cl.cout <= 32 && cl.cin % 64 == 0 && cl.cin <= 256 && cl.fragF >= 0;
+  }
   // the pre kernel's work of step tau + 1 rides in the head launch of step tau
   const bool pre_in_head = head_fused;
   WnGenStepArgs ga;
@@ -395,6 +408,26 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
         rc = wn_launch_gen_head(ha, s);
       }
       if (rc) return rc;
+    } else if (head_mix) {
+      WnGenHeadArgs ha;
+      memset(&ha, 0, sizeof(ha));
+      ha.params = params; ha.ws = workspace; ha.in_off = hin - workspace; ha.in_ld = hc; ha.out_off = G.last;
+      ha.nlayers = (int)(p->finals.size() - first_final - 1); ha.B = B;
+      ha.guard = gguard;
+      for (size_t i = first_final; i + 1 < p->finals.size(); ++i) {
+        const ConvInfo& c = p->finals[i];
+        const size_t l = i - first_final;
+        ha.w16_off[l] = G.prime + L.frag + c.frag16; ha.bias_off[l] = p->tensors[c.bias_t].off;
+        ha.K[l] = c.cin; ha.N[l] = c.cout; ha.act[l] = p->c.activation;
+      }
+      const ConvInfo& cl = p->finals.back();
+      ha.f32_w_off = G.prime + L.frag + cl.fragF; ha.f32_bias_off = p->tensors[cl.bias_t].off;
+      ha.f32_K = cl.cin; ha.f32_N = cl.cout;
+      ha.tail = deterministic ? 3 : 4; ha.mix_M = p->c.num_mixtures; ha.mix_kind = p->c.head;
+      ha.seed = seed; ha.offset = (uint64_t)step; ha.samp = samp;
+      ha.em = WnEmit{out, length, step, R.xin + (int64_t)((tau + 1) % p->KS) * B};
+      rc = wn_launch_gen_head(ha, s);
+      if (rc) return rc;
     } else {
     for (size_t i = first_final; i < p->finals.size(); ++i) {
       const ConvInfo& c = p->finals[i];
@@ -408,7 +441,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       hin = dst; hc = c.cout;
     }
     }
-    if (head_tail) {
+    if (head_tail || head_mix) {
       // sampled and emitted by the head launch
     } else if (p->c.head == WN_HEAD_CATEGORICAL && deterministic) {
       // softmax + arg max + emit in one launch

@@ -297,8 +297,13 @@ struct WnGenHeadArgs {
   int64_t bias_off[WN_GEN_HEAD_MAX];  // parameter offsets
   int32_t K[WN_GEN_HEAD_MAX], N[WN_GEN_HEAD_MAX], act[WN_GEN_HEAD_MAX];
   int32_t in_ld, nlayers, B;
-  // categorical sampling tail in the same launch: 0 none, 1 deterministic (arg max), 2 stochastic draw
-  int32_t tail;
+  // an exact-fp32 last layer behind the split-precision ones (f32_K > 0): the rows of wn_gemm_rows_kernel<1> -- at most 32
+  // columns, e.g. the 3 x mixtures outputs of a mixture head, which no split-precision image covers
+  int64_t f32_w_off, f32_bias_off; // fp32 fragment image (workspace offset), bias (parameter offset)
+  int32_t f32_K, f32_N;
+  // sampling tail in the same launch: 0 none, 1 categorical deterministic (arg max), 2 categorical stochastic draw,
+  // 3 mixture deterministic, 4 mixture stochastic (mix_M components, mix_kind 1 logistic / 2 gaussian)
+  int32_t tail, mix_M, mix_kind;
   float inv_lv;                    // 2 / levels
   uint64_t seed, offset;           // Philox key / counter word of a stochastic draw
   float* samp;                     // [B] samples (or null)

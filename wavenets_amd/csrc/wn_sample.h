@@ -155,3 +155,33 @@ __device__ __forceinline__ float wn_cat_rand_row(const float* l, int C, int lane
   const int result = wn_draw_cat_row((const float*)q, C, lane, row, seed, offset);
   return (float)result * inv_lv - 1.0f;
 }
+
+// Mixture heads (logistic / gaussian), one row per thread: src/model.py:423-503.  p = [M logit weights | M means | M log scales].
+__device__ __forceinline__ float wn_mix_det_row(const float* p, int M) {
+  int bi = 0;
+  float best = p[0];
+  for (int k = 1; k < M; ++k) if (p[k] > best) { best = p[k]; bi = k; }
+  return fminf(fmaxf(p[M + bi], -1.0f), 1.0f);
+}
+__device__ __forceinline__ float wn_mix_rand_row(const float* p, int M, int kind, int64_t row, uint64_t seed, uint64_t offset) {
+  uint32_t r[4];
+  wn_philox((uint64_t)row, offset, seed, r);
+  float wm = -INFINITY;
+  for (int k = 0; k < M; ++k) wm = fmaxf(wm, p[k]);
+  float wz = 0.f;
+  for (int k = 0; k < M; ++k) wz += expf(p[k] - wm);
+  const float target = wn_u01(r[0]) * wz;
+  int sel = M - 1;
+  float run = 0.f;
+  for (int k = 0; k < M; ++k) { run += expf(p[k] - wm); if (run > target) { sel = k; break; } }
+  const float mu = p[M + sel], sc = expf(p[2 * M + sel]);
+  float v;
+  if (kind == 1) {                       // logistic: mu + s (ln z - ln(1-z))     src/model.py:463-483
+    const float zz = wn_u01(r[1]);
+    v = mu + sc * (logf(zz) - logf(1.0f - zz));
+  } else {                               // gaussian: mu + s n                   src/model.py:423-443
+    const float u1 = wn_u01(r[1]), u2 = wn_u01(r[2]);
+    v = mu + sc * sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+  return fminf(fmaxf(v, -1.0f), 1.0f);
+}
