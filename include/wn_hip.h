@@ -76,14 +76,28 @@ typedef struct wn_plan wn_plan;
 const char* wn_last_error_string(void);
 
 /* ---- plan (WaveNet.__init__ + build, src/model.py:14-211).  The network description inside a plan (shapes, dilation
- * schedule, tensor table, image layouts) is immutable after wn_plan_create.  A plan ALSO carries per-caller launch state
- * that the calls below set and the entry points read: the dropout counter (wn_plan_set_dropout), the armed step-sample
- * pointer (wn_plan_arm_step_sample), the phase selection (wn_plan_set_train_phases), its side stream / events and the
- * measurement hooks (wn_prof_*, wn_stack_prof_*, wn_phase_*), plus device-side job tables cached per (B, T).  A plan
- * therefore serves ONE stream / one thread at a time; callers that drive several streams create one plan per stream
- * (plans are cheap: no device memory besides the job tables). ---- */
+ * schedule, tensor table, image layouts, workspace layouts) is immutable after wn_plan_create; device copies of its small
+ * tables are made once, on first use, under a lock.  The per-caller launch state the calls below set and the entry
+ * points read -- dropout counter (wn_plan_set_dropout), armed step-sample pointer (wn_plan_arm_step_sample), phase
+ * selection (wn_plan_set_train_phases), side stream / events, measurement hooks (wn_prof_*, wn_stack_prof_*, wn_phase_*),
+ * device-side job tables cached per (B, T) -- is NOT in the plan but in an execution state (wn_exec, below): the
+ * plan's own by default, or the one the calling thread has bound.  The setters named wn_plan_* act on that state. ---- */
 wn_plan* wn_plan_create(const wn_config* cfg);          /* NULL on error */
 void wn_plan_destroy(wn_plan* p);
+
+/* Execution state.  A wn_plan is immutable once created (configuration, tensor table, weight-image layouts, workspace
+ * layouts) and may be shared by any number of host threads and streams.  What changes while a plan is
+ * USED -- the dropout counter, the armed step sample, the phase selection, the weight-gradient job tables and generation
+ * block table cached for the last (B, T) (device memory), the side stream and its events, the profiling events -- lives
+ * in a wn_exec.  Every plan carries one of its own, used by callers that never bind another: the single-threaded use of
+ * the reference (one Python thread drives everything, train.py:203-258) needs nothing below.  A caller that drives ONE
+ * plan from several threads / streams creates one wn_exec per thread and binds it there; the binding is thread-local
+ * and applies to calls on the plan the state was created for.  A new state copies the dropout setting and phase
+ * selection the plan's own state has at that moment.  wn_exec_bind(NULL) unbinds. */
+typedef struct wn_exec wn_exec;
+wn_exec* wn_exec_create(const wn_plan* p);
+void wn_exec_destroy(wn_exec* e);
+int wn_exec_bind(wn_exec* e);
 int64_t wn_plan_param_count(const wn_plan* p);
 int32_t wn_plan_num_tensors(const wn_plan* p);
 /* tensor idx in Keras creation order: flat offset, element count, rank, shape[3] */

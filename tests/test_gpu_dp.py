@@ -185,3 +185,63 @@ def test_bench_multi_rank_plumbing_rehearsal():
   assert out['config']['global_batch'] == 4 and out['config']['parallelism'] == 'dp2'
   assert out['value'] > 0 and abs(out['value'] - 4 * 3500 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-6 * out['value']
   assert out['roofline']['frac'] > 0 and 'cpu_baseline' not in out
+
+
+def test_one_plan_shared_by_two_threads_and_streams():
+  """a wn_plan is immutable and shareable across streams.  Two host threads drive ONE plan at the same
+  time, each with its own execution state (wn_exec_create / wn_exec_bind), its own HIP stream, its own shape (so each
+  caches different weight-gradient job tables), workspace and gradient buffer: losses and gradients are bit-identical to
+  the same two calls made one after the other through the plan's own state."""
+  import threading
+  import torch
+  from wavenets_amd import WaveNet, _lib
+  from oracle import wavenet_oracle as O          # synthetic input generator only
+  dev = torch.device('cuda', 0)
+  kw = dict(blocks=6, channels=64, skip_channels=256, dilation_bound=32, final_layers_channels=[128, 256],
+            activation='leaky_relu', bits=8)
+  model = WaveNet(**kw, device=dev, seed=11)
+  model.build((1, 8, 1))
+  L = _lib.lib()
+  shapes = [(3, 700), (2, 1333)]
+  xs = [O.synthetic_waveform(B, T + 1, seed=5 + i).to(dev) for i, (B, T) in enumerate(shapes)]
+
+  def call(i, stream_ptr):
+    B, T = shapes[i]
+    n = L.wn_plan_workspace_floats(model._plan, B, T, 1)
+    ws = torch.empty(n, dtype=torch.float32, device=dev)
+    grads = torch.zeros_like(model.flat_params)
+    loss = torch.zeros(3, dtype=torch.float32, device=dev)
+    for _ in range(3):                              # (repeated: the cached tables are reused, then nothing changes)
+      _lib.check(L.wn_train_fwd_bwd(model._plan, _lib.ptr(model.flat_params), _lib.ptr(xs[i]), None, B, T, B, 1,
+                                    _lib.ptr(grads), _lib.ptr(loss), None, _lib.ptr(ws), ws.numel(), stream_ptr))
+    return loss, grads, ws
+
+  ref = []
+  for i in range(2):
+    with torch.cuda.stream(torch.cuda.current_stream()):
+      ref.append(call(i, _lib.stream_ptr())[:2])
+  torch.cuda.synchronize()
+  ref = [(l.clone(), g.clone()) for l, g in ref]
+
+  out, errs = [None, None], []
+  def worker(i):
+    try:
+      torch.cuda.set_device(0)
+      ex = L.wn_exec_create(model._plan)
+      assert ex
+      L.wn_exec_bind(ex)
+      st = torch.cuda.Stream()
+      with torch.cuda.stream(st):
+        out[i] = call(i, st.cuda_stream)
+      st.synchronize()
+      L.wn_exec_bind(None)
+      L.wn_exec_destroy(ex)
+    except Exception as e:                          # noqa: BLE001
+      errs.append(e)
+  ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+  for t in ths: t.start()
+  for t in ths: t.join()
+  assert not errs, errs
+  torch.cuda.synchronize()
+  for i in range(2):
+    assert torch.equal(out[i][0], ref[i][0]) and torch.equal(out[i][1], ref[i][1]), i

@@ -69,6 +69,9 @@ _SIGS = {
     'wn_plan_dilation': (C.c_int32, [_P, C.c_int32]),
     'wn_plan_workspace_floats': (C.c_int64, [_P, C.c_int32, C.c_int32, C.c_int32]),
     'wn_debug_set': (C.c_int, [C.c_int, C.c_int]),
+    'wn_exec_create': (_P, [_P]),
+    'wn_exec_destroy': (None, [_P]),
+    'wn_exec_bind': (C.c_int, [_P]),
     'wn_debug_value': (C.c_int, [C.c_int]),
     'wn_debug_gen_ts': (C.c_int, [_P]),
     'wn_plan_set_dropout': (C.c_int, [_P, C.c_float, C.c_uint64, C.c_uint64]),

@@ -33,7 +33,7 @@ extern "C" int wn_plan_arm_step_sample(wn_plan* p, float* sample_out, int32_t de
     wn_set_error("arm_step_sample: categorical head needs a stochastic draw over <= 1024 classes");
     return WN_E_UNSUPPORTED;
   }
-  p->step_sample = sample_out; p->step_sample_det = deterministic; p->step_sample_seed = seed; p->step_sample_off = offset;
+  wnp::ex(p).step_sample = sample_out; wnp::ex(p).step_sample_det = deterministic; wnp::ex(p).step_sample_seed = seed; wnp::ex(p).step_sample_off = offset;
   return WN_OK;
 }
 extern "C" int wn_sample_waveform(int32_t head, const float* pred, int64_t rows, int32_t C, int32_t num_mixtures,

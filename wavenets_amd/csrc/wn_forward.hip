@@ -86,8 +86,8 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = wn_launch_prep_table(p->d_prep, (int)p->prep.size(), params, fragbase, s);
     if (rc) return rc;
   }
-  const bool fp_prof = prep && fold_ok(p) && p->foldprep_used + 2 <= (int)p->foldprep_ev.size();
-  if (fp_prof) (void)hipEventRecord(p->foldprep_ev[p->foldprep_used], s);
+  const bool fp_prof = prep && fold_ok(p) && wnp::ex(p).foldprep_used + 2 <= (int)wnp::ex(p).foldprep_ev.size();
+  if (fp_prof) (void)hipEventRecord(wnp::ex(p).foldprep_ev[wnp::ex(p).foldprep_used], s);
   // bias of the folded skip sum = sum over blocks of conv_skip (or conv1) biases
   if (prep && p->c.use_skip) {
     const ConvInfo& c0 = p->blocks[0].has_skip ? p->blocks[0].conv_skip : p->blocks[0].conv1;
@@ -111,7 +111,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = wn_launch_prep_table(p->d_prep2, (int)p->prep2.size(), ws, fragbase, s, 64);  // sources relative to the workspace
     if (rc) return rc;
   }
-  if (fp_prof) { (void)hipEventRecord(p->foldprep_ev[p->foldprep_used + 1], s); p->foldprep_used += 2; }
+  if (fp_prof) { (void)hipEventRecord(wnp::ex(p).foldprep_ev[wnp::ex(p).foldprep_used + 1], s); wnp::ex(p).foldprep_used += 2; }
   // conditioning: mapping Dense stack + per-block time-invariant bias  (src/model.py:221-225,
   // src/layers.py:203-204: conv_cond(repeat(m)) == per-utterance bias)
   const float* m = cond;
@@ -183,10 +183,10 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   }
   // residual blocks, src/model.py:230-234
   // profiling: is the chain N back-to-back launches of the fused block kernel?
-  const bool prof_chain = p->prof_on && !rings && p->LPB == 1 && p->c.cond_inputs == 0 && p->R == p->D &&
-                          !(training && p->drop_rate > 0.f) && block_ptrs(p, 0, params, fragbase, B, T).fused;
-  const bool stack_prof = !rings && p->stack_used + 2 <= (int)p->stack_ev.size();
-  if (stack_prof) (void)hipEventRecord(p->stack_ev[p->stack_used], s);
+  const bool prof_chain = wnp::ex(p).prof_on && !rings && p->LPB == 1 && p->c.cond_inputs == 0 && p->R == p->D &&
+                          !(training && wnp::ex(p).drop_rate > 0.f) && block_ptrs(p, 0, params, fragbase, B, T).fused;
+  const bool stack_prof = !rings && wnp::ex(p).stack_used + 2 <= (int)wnp::ex(p).stack_ev.size();
+  if (stack_prof) (void)hipEventRecord(wnp::ex(p).stack_ev[wnp::ex(p).stack_used], s);
   for (int b = 0; b < p->N; ++b) {
     BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
     if (training && !rings) deep16_ptrs(p, b, fragbase, k);
@@ -195,10 +195,10 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     memset(&f, 0, sizeof(f));
     const int hi = training ? b : (b & 1), ho = training ? b + 1 : ((b + 1) & 1);
     f.x = ws + L.H[hi];
-    if (training && p->drop_rate > 0.f) {
+    if (training && wnp::ex(p).drop_rate > 0.f) {
       // x = dropout(x) feeds the dilated stack; the residual keeps the original (src/layers.py:192-196)
-      rc = wn_launch_dropout(ws + L.H[hi], nullptr, ws + L.XD[b], rows * p->R, p->drop_rate,
-                             wn_dropout_key(p->drop_seed, b, p->drop_step), nullptr, s);
+      rc = wn_launch_dropout(ws + L.H[hi], nullptr, ws + L.XD[b], rows * p->R, wnp::ex(p).drop_rate,
+                             wn_dropout_key(wnp::ex(p).drop_seed, b, wnp::ex(p).drop_step), nullptr, s);
       if (rc) return rc;
       f.x = ws + L.XD[b];
       f.res = ws + L.H[hi];
@@ -210,15 +210,15 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     f.O = nullptr;
     f.x_out = ws + L.H[ho];
     f.fwd_absmax = fam;
-    const bool prof = p->prof_on && p->prof_used + 2 <= (int)p->prof_ev.size();
+    const bool prof = wnp::ex(p).prof_on && wnp::ex(p).prof_used + 2 <= (int)wnp::ex(p).prof_ev.size();
     const bool ev0 = prof && (!prof_chain || b == 0), ev1 = prof && (!prof_chain || b == p->N - 1);
-    if (ev0) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
+    if (ev0) (void)hipEventRecord(wnp::ex(p).prof_ev[wnp::ex(p).prof_used], s);
     rc = block_forward(k, f, s);
     if (rc) return rc;
     if (ev1) {
-      (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
-      p->prof_cnt[p->prof_used / 2] = prof_chain ? p->N : 1;
-      p->prof_used += 2;
+      (void)hipEventRecord(wnp::ex(p).prof_ev[wnp::ex(p).prof_used + 1], s);
+      wnp::ex(p).prof_cnt[wnp::ex(p).prof_used / 2] = prof_chain ? p->N : 1;
+      wnp::ex(p).prof_used += 2;
     }
     if (rings && b + 1 < p->N) {
       rc = ring_capture(f.x_out, B, T, p->R, rings->nslots[b + 1], rings->h[b + 1], s);
@@ -263,7 +263,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
   } else {
     hin = ws + L.H[training ? p->N : (p->N & 1)];
   }
-  if (stack_prof) { (void)hipEventRecord(p->stack_ev[p->stack_used + 1], s); p->stack_used += 2; }
+  if (stack_prof) { (void)hipEventRecord(wnp::ex(p).stack_ev[wnp::ex(p).stack_used + 1], s); wnp::ex(p).stack_used += 2; }
   // head, src/model.py:105-119,237-238: conv -> activation, last conv linear (softmax applied later)
   int hc = fold ? p->finals[0].cout : p->Hin;
   for (size_t i = first_final; i < p->finals.size(); ++i) {
@@ -338,10 +338,10 @@ int loss_stage(wn_plan* p, int B, int T, int global_batch, bool want_grad, float
     if (rc) return rc;
     // an armed step sample (wn_plan_arm_step_sample) rides in the loss kernel when the row fits its registers
     float* so = nullptr;
-    if (want_grad && p->step_sample && !p->step_sample_det && p->Cout <= 256) { so = p->step_sample; p->step_sample = nullptr; }
+    if (want_grad && wnp::ex(p).step_sample && !wnp::ex(p).step_sample_det && p->Cout <= 256) { so = wnp::ex(p).step_sample; wnp::ex(p).step_sample = nullptr; }
     rc = wn_launch_cat_loss(ws + L.logits, reinterpret_cast<const int32_t*>(ws + L.target), rows, p->Cout,
-                            gscale, ws + L.loss_rows, g_logits, absmax_out, s, so, p->c.bits, p->step_sample_seed,
-                            p->step_sample_off);
+                            gscale, ws + L.loss_rows, g_logits, absmax_out, s, so, p->c.bits, wnp::ex(p).step_sample_seed,
+                            wnp::ex(p).step_sample_off);
   } else {
     rc = wn_launch_mix_loss(ws + L.logits, ws + L.yt, rows, p->c.num_mixtures, p->c.bits,
                             p->c.head == WN_HEAD_LOGISTIC ? 1 : 2, gscale, ws + L.loss_rows, g_logits, absmax_out, s);

@@ -214,8 +214,8 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   const bool relay128 = chain128 && G.relay >= 0 && wn_debug_get(2) == 0 && (int64_t)((B + 31) / 32) * p->N <= cu_count;
   if (relay128)   // every granule tag starts below the first epoch
     WN_HIP_CHECK(hipMemsetAsync(workspace + G.relay, 0, (size_t)wn_gen_relay128_floats(B, p->N) * sizeof(float), s));
-  if ((fused_step || chain128) && (!p->d_gen || p->gen_B != B || p->gen_chain128 != chain128)) {
-    p->gen_chain128 = chain128;
+  if ((fused_step || chain128) && (!wnp::ex(p).d_gen || wnp::ex(p).gen_B != B || wnp::ex(p).gen_chain128 != chain128)) {
+    wnp::ex(p).gen_chain128 = chain128;
     std::vector<WnGenBlock> tab(p->N);
     for (int b = 0; b < p->N; ++b) {
       const BlockInfo& bi = p->blocks[b];
@@ -229,15 +229,15 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
       g.nslots = G.nslots[b];
       g.dilation = bi.dil.back().dil;
     }
-    if (p->d_gen) { (void)hipFree(p->d_gen); p->d_gen = nullptr; }
-    WN_HIP_CHECK(hipMalloc((void**)&p->d_gen, tab.size() * sizeof(WnGenBlock)));
-    WN_HIP_CHECK(hipMemcpy(p->d_gen, tab.data(), tab.size() * sizeof(WnGenBlock), hipMemcpyHostToDevice));
-    p->gen_B = B;
-    for (int b = 0; b < 3; ++b) p->gen_blk0[b] = tab[std::min(b, p->N - 1)];
+    if (wnp::ex(p).d_gen) { (void)hipFree(wnp::ex(p).d_gen); wnp::ex(p).d_gen = nullptr; }
+    WN_HIP_CHECK(hipMalloc((void**)&wnp::ex(p).d_gen, tab.size() * sizeof(WnGenBlock)));
+    WN_HIP_CHECK(hipMemcpy(wnp::ex(p).d_gen, tab.data(), tab.size() * sizeof(WnGenBlock), hipMemcpyHostToDevice));
+    wnp::ex(p).gen_B = B;
+    for (int b = 0; b < 3; ++b) wnp::ex(p).gen_blk0[b] = tab[std::min(b, p->N - 1)];
     // conv1 biases at a uniform stride (every block has the same tensors): the chain kernel fetches them without the table
-    p->gen_bias_stride = p->N > 1 ? tab[1].bias_r_off - tab[0].bias_r_off : 1;
+    wnp::ex(p).gen_bias_stride = p->N > 1 ? tab[1].bias_r_off - tab[0].bias_r_off : 1;
     for (int b = 1; b < p->N; ++b)
-      if (tab[b].bias_r_off != tab[0].bias_r_off + (int64_t)b * p->gen_bias_stride) p->gen_bias_stride = 0;
+      if (tab[b].bias_r_off != tab[0].bias_r_off + (int64_t)b * wnp::ex(p).gen_bias_stride) wnp::ex(p).gen_bias_stride = 0;
   }
   const int hc0 = (gfold && p->c.use_skip) ? skipw : p->Hin;
   // the whole head in one launch when every layer is one the split-precision rows GEMM would take
@@ -267,12 +267,12 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
   for (int step = 1; step < length; ++step) {
     const int64_t tau = (int64_t)RF + step - 1;        // time of the newest known sample
     if (fused_step) {
-      ga.params = params; ga.ws = workspace; ga.blocks = p->d_gen; ga.xin = R.xin;
+      ga.params = params; ga.ws = workspace; ga.blocks = wnp::ex(p).d_gen; ga.xin = R.xin;
       ga.causal_w = params + p->tensors[p->causal.kernel_t].off;
       ga.causal_b = params + p->tensors[p->causal.bias_t].off;
       ga.u0_off = G.u0;
-      for (int b = 0; b < 3; ++b) ga.blk0[b] = p->gen_blk0[b];
-      ga.bias_r_off0 = p->gen_blk0[0].bias_r_off; ga.bias_r_stride = p->gen_bias_stride;
+      for (int b = 0; b < 3; ++b) ga.blk0[b] = wnp::ex(p).gen_blk0[b];
+      ga.bias_r_off0 = wnp::ex(p).gen_blk0[0].bias_r_off; ga.bias_r_stride = wnp::ex(p).gen_bias_stride;
       if (skip_in_chain) {
         ga.skip_w16_off = G.prime + L.frag + skip_img;
         ga.skip_bias_off = G.prime + (gfold ? L.bfold : L.bias_sum);
@@ -300,7 +300,7 @@ extern "C" int wn_generate(wn_plan* p, const float* params, const float* window,
     if (chain128) {
       WnGen128Args ca;
       memset(&ca, 0, sizeof(ca));
-      ca.params = params; ca.ws = workspace; ca.blocks = p->d_gen; ca.zrow_off = G.Zrow;
+      ca.params = params; ca.ws = workspace; ca.blocks = wnp::ex(p).d_gen; ca.zrow_off = G.Zrow;
       ca.hrow_off = p->c.use_skip ? -1 : G.hrow0; ca.tau = tau; ca.B = B; ca.nblocks = p->N; ca.residual = p->c.use_residual;
       ca.guard = gguard;
       if (inconv_in_chain) {

@@ -128,8 +128,35 @@ int64_t slab_need(int B, int T, int K, int N) {
   return (int64_t)B * sp * ((int64_t)K * N + N);
 }
 
+// thread-local: the execution state this host thread has bound (wn_exec_bind), or null
+static thread_local wn_exec* g_bound_exec = nullptr;
+wn_exec& ex(const wn_plan* p) {
+  return (g_bound_exec && g_bound_exec->plan == p) ? *g_bound_exec : *p->own;
+}
+
+void exec_release(wn_exec* e) {
+  if (!e) return;
+  for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->stack_ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->foldprep_ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->phase_ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->d_jobs) (void)hipFree(e->d_jobs);
+  if (e->d_cov) (void)hipFree(e->d_cov);
+  if (e->d_wgl) (void)hipFree(e->d_wgl);
+  if (e->d_wgli) (void)hipFree(e->d_wgli);
+  if (e->d_pairs) (void)hipFree(e->d_pairs);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->d_gen) (void)hipFree(e->d_gen);
+  if (g_bound_exec == e) g_bound_exec = nullptr;
+  delete e;
+}
+
+// device copies of the plan's immutable tables: made once, by whichever caller needs them first
 int ensure_device_tables(wn_plan* p) {
-  if (p->d_prep) return WN_OK;
+  std::lock_guard<std::mutex> lock(p->tables_mu);
+  if (p->tables_ready) return WN_OK;
   WN_HIP_CHECK(hipMalloc((void**)&p->d_prep, p->prep.size() * sizeof(WnPrepDesc)));
   WN_HIP_CHECK(hipMemcpy(p->d_prep, p->prep.data(), p->prep.size() * sizeof(WnPrepDesc), hipMemcpyHostToDevice));
   WN_HIP_CHECK(hipMalloc((void**)&p->d_tdesc, p->tdesc.size() * sizeof(WnTensorDesc)));
@@ -147,6 +174,7 @@ int ensure_device_tables(wn_plan* p) {
     WN_HIP_CHECK(hipMemcpy(p->d_cov_fold, &d, sizeof(WnTensorDesc), hipMemcpyHostToDevice));
     p->h_cov_fold = d;
   }
+  p->tables_ready = true;
   return WN_OK;
 }
 
@@ -240,7 +268,7 @@ WsLayout make_layout(const wn_plan* p, int B, int T, bool training) {
     L.cb = L.dcb = L.g_m0 = L.g_m1 = L.cbt = 0;
   }
   L.gxd = 0;
-  if (training && p->drop_rate > 0.f) {
+  if (training && wnp::ex(p).drop_rate > 0.f) {
     for (int b = 0; b < p->N; ++b) L.XD.push_back(cv.take(rows * p->R));
     L.gxd = cv.take(rows * p->R);
   }
@@ -573,6 +601,8 @@ extern "C" wn_plan* wn_plan_create(const wn_config* cfg) {
     for (int b = 0; b < p->N; ++b)                                               // A[c][R + n] = V[b*D + c][n]
       piece2(p->blocks[b].g16uf, p->D, voff + (int64_t)b * p->D * F0, F0, F0, 0, p->R / 16);
   }
+  p->own = new wn_exec;
+  p->own->plan = p;
   return p;
 }
 
@@ -583,26 +613,30 @@ extern "C" void wn_plan_destroy(wn_plan* p) {
   if (p->d_kdesc) (void)hipFree(p->d_kdesc);
   if (p->d_prep2) (void)hipFree(p->d_prep2);
   if (p->d_cov_fold) (void)hipFree(p->d_cov_fold);
-  for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : p->stack_ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : p->foldprep_ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : p->phase_ev) if (e) (void)hipEventDestroy(e);
-  if (p->d_jobs) (void)hipFree(p->d_jobs);
-  if (p->d_cov) (void)hipFree(p->d_cov);
-  if (p->d_wgl) (void)hipFree(p->d_wgl);
-  if (p->d_wgli) (void)hipFree(p->d_wgli);
-  if (p->d_pairs) (void)hipFree(p->d_pairs);
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-  if (p->side) (void)hipStreamDestroy(p->side);
-  if (p->d_gen) (void)hipFree(p->d_gen);
+  wnp::exec_release(p->own);
   delete p;
+}
+
+// ---- execution states: one per host thread / stream that drives the same plan (see struct wn_exec) ----
+extern "C" wn_exec* wn_exec_create(const wn_plan* p) {
+  if (!p) { wn_set_error("exec_create: null plan"); return nullptr; }
+  wn_exec* e = new wn_exec;
+  e->plan = p;
+  // a new state starts from the plan's own dropout setting and phase selection (what the Python layer configured)
+  e->drop_rate = p->own->drop_rate; e->drop_seed = p->own->drop_seed; e->drop_step = p->own->drop_step;
+  e->train_phases = p->own->train_phases;
+  return e;
+}
+extern "C" void wn_exec_destroy(wn_exec* e) { wnp::exec_release(e); }
+extern "C" int wn_exec_bind(wn_exec* e) {
+  wnp::g_bound_exec = e;
+  return WN_OK;
 }
 
 // ---- Dropout(rate) on every block input in training mode (src/layers.py:108-111, 195-196) ----
 extern "C" int wn_plan_set_dropout(wn_plan* p, float rate, uint64_t seed, uint64_t step) {
   if (!p || rate < 0.f || rate >= 1.f) { wn_set_error("Dropout must be between 0 and 1."); return WN_E_INVALID; }
-  p->drop_rate = rate; p->drop_seed = seed; p->drop_step = step;
+  wnp::ex(p).drop_rate = rate; wnp::ex(p).drop_seed = seed; wnp::ex(p).drop_step = step;
   return WN_OK;
 }
 extern "C" uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t step) { return wn_dropout_key(seed, block, step); }
@@ -613,33 +647,33 @@ extern "C" uint32_t wn_dropout_key_for(uint64_t seed, int32_t block, uint64_t st
 //      (+5 us per launch on MI355X) to what it measures.  Otherwise one pair per block. ----
 extern "C" int wn_prof_enable(wn_plan* p, int32_t max_launches) {
   if (!p) return WN_E_INVALID;
-  for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
-  p->prof_ev.clear();
-  p->prof_cnt.assign(max_launches > 0 ? max_launches : 0, 1);
-  p->prof_used = 0;
-  p->prof_on = max_launches > 0;
+  for (hipEvent_t e : wnp::ex(p).prof_ev) (void)hipEventDestroy(e);
+  wnp::ex(p).prof_ev.clear();
+  wnp::ex(p).prof_cnt.assign(max_launches > 0 ? max_launches : 0, 1);
+  wnp::ex(p).prof_used = 0;
+  wnp::ex(p).prof_on = max_launches > 0;
   for (int i = 0; i < 2 * max_launches; ++i) {
     hipEvent_t e;
     WN_HIP_CHECK(hipEventCreate(&e));
-    p->prof_ev.push_back(e);
+    wnp::ex(p).prof_ev.push_back(e);
   }
   return WN_OK;
 }
 // ---- the whole block stack: one event pair per forward pass, first block launch -> end of the folded skip sum ----
 extern "C" int wn_stack_prof_enable(wn_plan* p, int32_t max_passes) {
   if (!p) return WN_E_INVALID;
-  for (hipEvent_t e : p->stack_ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : p->foldprep_ev) (void)hipEventDestroy(e);
-  p->stack_ev.clear();
-  p->foldprep_ev.clear();
-  p->stack_used = 0;
-  p->foldprep_used = 0;
+  for (hipEvent_t e : wnp::ex(p).stack_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : wnp::ex(p).foldprep_ev) (void)hipEventDestroy(e);
+  wnp::ex(p).stack_ev.clear();
+  wnp::ex(p).foldprep_ev.clear();
+  wnp::ex(p).stack_used = 0;
+  wnp::ex(p).foldprep_used = 0;
   for (int i = 0; i < 2 * max_passes; ++i) {
     hipEvent_t e;
     WN_HIP_CHECK(hipEventCreate(&e));
-    p->stack_ev.push_back(e);
+    wnp::ex(p).stack_ev.push_back(e);
     WN_HIP_CHECK(hipEventCreate(&e));
-    p->foldprep_ev.push_back(e);
+    wnp::ex(p).foldprep_ev.push_back(e);
   }
   return WN_OK;
 }
@@ -649,42 +683,42 @@ extern "C" int wn_stack_prof_read_foldprep(wn_plan* p, int32_t* passes, float* a
   if (!p || !passes || !avg_ms) return WN_E_INVALID;
   double tot = 0.0;
   int n = 0;
-  for (int i = 0; i + 1 < p->foldprep_used; i += 2) {
+  for (int i = 0; i + 1 < wnp::ex(p).foldprep_used; i += 2) {
     float ms = 0.f;
-    WN_HIP_CHECK(hipEventElapsedTime(&ms, p->foldprep_ev[i], p->foldprep_ev[i + 1]));
+    WN_HIP_CHECK(hipEventElapsedTime(&ms, wnp::ex(p).foldprep_ev[i], wnp::ex(p).foldprep_ev[i + 1]));
     tot += ms; ++n;
   }
   *passes = n;
   *avg_ms = n ? (float)(tot / n) : 0.f;
-  p->foldprep_used = 0;
+  wnp::ex(p).foldprep_used = 0;
   return WN_OK;
 }
 extern "C" int wn_stack_prof_read(wn_plan* p, int32_t* passes, float* avg_ms) {
   if (!p || !passes || !avg_ms) return WN_E_INVALID;
   double tot = 0.0;
   int n = 0;
-  for (int i = 0; i + 1 < p->stack_used; i += 2) {
+  for (int i = 0; i + 1 < wnp::ex(p).stack_used; i += 2) {
     float ms = 0.f;
-    WN_HIP_CHECK(hipEventElapsedTime(&ms, p->stack_ev[i], p->stack_ev[i + 1]));
+    WN_HIP_CHECK(hipEventElapsedTime(&ms, wnp::ex(p).stack_ev[i], wnp::ex(p).stack_ev[i + 1]));
     tot += ms; ++n;
   }
   *passes = n;
   *avg_ms = n ? (float)(tot / n) : 0.f;
-  p->stack_used = 0;
+  wnp::ex(p).stack_used = 0;
   return WN_OK;
 }
 // ---- phase marks of wn_train_fwd_bwd (bench.py): events after the forward, the loss, the backward-data
 //      chain and at the end; wn_phase_read returns the four durations of the LAST call in milliseconds ----
 extern "C" int wn_phase_enable(wn_plan* p, int32_t on) {
   if (!p) return WN_E_INVALID;
-  if (on && !p->phase_ev[0])
-    for (hipEvent_t& e : p->phase_ev) WN_HIP_CHECK(hipEventCreate(&e));
-  p->phase_on = on != 0;
+  if (on && !wnp::ex(p).phase_ev[0])
+    for (hipEvent_t& e : wnp::ex(p).phase_ev) WN_HIP_CHECK(hipEventCreate(&e));
+  wnp::ex(p).phase_on = on != 0;
   return WN_OK;
 }
 extern "C" int wn_phase_read(wn_plan* p, float* ms4) {
-  if (!p || !ms4 || !p->phase_ev[0]) return WN_E_INVALID;
-  for (int i = 0; i < 4; ++i) WN_HIP_CHECK(hipEventElapsedTime(ms4 + i, p->phase_ev[i], p->phase_ev[i + 1]));
+  if (!p || !ms4 || !wnp::ex(p).phase_ev[0]) return WN_E_INVALID;
+  for (int i = 0; i < 4; ++i) WN_HIP_CHECK(hipEventElapsedTime(ms4 + i, wnp::ex(p).phase_ev[i], wnp::ex(p).phase_ev[i + 1]));
   return WN_OK;
 }
 // average milliseconds per recorded launch (call after the stream has been synchronised)
@@ -692,14 +726,14 @@ extern "C" int wn_prof_read(wn_plan* p, int32_t* launches, float* avg_ms) {
   if (!p || !launches || !avg_ms) return WN_E_INVALID;
   double tot = 0.0;
   int n = 0;
-  for (int i = 0; i + 1 < p->prof_used; i += 2) {
+  for (int i = 0; i + 1 < wnp::ex(p).prof_used; i += 2) {
     float ms = 0.f;
-    WN_HIP_CHECK(hipEventElapsedTime(&ms, p->prof_ev[i], p->prof_ev[i + 1]));
-    tot += ms; n += p->prof_cnt[i / 2];
+    WN_HIP_CHECK(hipEventElapsedTime(&ms, wnp::ex(p).prof_ev[i], wnp::ex(p).prof_ev[i + 1]));
+    tot += ms; n += wnp::ex(p).prof_cnt[i / 2];
   }
   *launches = n;
   *avg_ms = n ? (float)(tot / n) : 0.f;
-  p->prof_used = 0;
+  wnp::ex(p).prof_used = 0;
   return WN_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/wn_hip.h"
@@ -53,38 +54,15 @@ struct BlockInfo {
 
 }  // namespace wnp
 
-struct wn_plan {
-  wn_config c;
-  int KS, R, D, S, N, LPB, Cout, Sh, Hin, Cc, Dp;
-  std::vector<int> dilations;
-  std::vector<wnp::TensorInfo> tensors;
-  int64_t nparams = 0;
-  wnp::ConvInfo causal;
-  std::vector<wnp::BlockInfo> blocks;
-  std::vector<wnp::ConvInfo> finals, mapping;
-  int64_t frag_skipF = -1;     // A[Sh][N*Dp] image of the folded skip sum
-  // all blocks' conv_cond as one layer (when every block has one and 2D % 32 == 0): forward image
-  // A[N*2D][Cc], backward image A[Cc][N*2D]; -1 = per-block path
-  int64_t frag_condF = -1, frag_condB = -1;
-  int64_t frag16_skipF = -1;   // the same as an fp16 split image, or -1
-  int64_t frag_floats = 0;
-  // skip path folded into the head's first convolution (training passes; see wn_skip_fold_kernel): F0 = its width,
-  // forward image A[F0][N*D] of V^T.  prep2 = pieces whose SOURCE is the workspace (the V matrix), not the parameters
-  int fold_F0 = 0;
-  int64_t frag16_foldF = -1;
-  std::vector<WnPrepDesc> prep2;
-  WnPrepDesc* d_prep2 = nullptr;
-  WnTensorDesc* d_cov_fold = nullptr;
-  WnTensorDesc h_cov_fold = {0, 0};     // host copies of the coverage tables (the flattened reduce sizes its grid from them)
-  std::vector<WnTensorDesc> h_cov;
-  std::vector<WnPrepDesc> prep;
-  std::vector<WnTensorDesc> tdesc, kdesc;
-  // device copies (lazy)
-  WnPrepDesc* d_prep = nullptr;
-  WnTensorDesc* d_tdesc = nullptr;
-  WnTensorDesc* d_kdesc = nullptr;
-  bool fused_ok = false, fused16_ok = false;
-  bool deep16_ok = false;      // layers_per_block > 1: split-precision images of the whole stack exist
+// The mutable side of a plan: per-caller state of the orchestration ("a wn_plan is immutable and shareable
+// across streams").  One per stream of execution: dropout counter, the armed step sample, phase selection, the cached
+// weight-gradient job tables and generation block table of the last (B, T) it ran (device memory it owns), its side
+// stream and events, its profiling events.  A caller that drives one plan from several host threads / streams creates
+// one wn_exec per thread (wn_exec_create) and binds it there (wn_exec_bind: thread-local); unbound callers share the
+// plan's own.
+struct wn_exec {
+  const struct wn_plan* plan = nullptr;
+  std::vector<WnTensorDesc> h_cov;      // host copy of the coverage table of the cached jobs (the flattened reduce sizes its grid from it)
   float drop_rate = 0.f;        // Dropout rate applied to every block input in training (src/layers.py:108-111)
   uint64_t drop_seed = 0, drop_step = 0;
   // armed by wn_plan_arm_step_sample: the next training step also draws sample_waveform(pred)
@@ -136,7 +114,51 @@ struct wn_plan {
   int stack_used = 0;
 };
 
+struct wn_plan {
+  wn_config c;
+  int KS, R, D, S, N, LPB, Cout, Sh, Hin, Cc, Dp;
+  std::vector<int> dilations;
+  std::vector<wnp::TensorInfo> tensors;
+  int64_t nparams = 0;
+  wnp::ConvInfo causal;
+  std::vector<wnp::BlockInfo> blocks;
+  std::vector<wnp::ConvInfo> finals, mapping;
+  int64_t frag_skipF = -1;     // A[Sh][N*Dp] image of the folded skip sum
+  // all blocks' conv_cond as one layer (when every block has one and 2D % 32 == 0): forward image
+  // A[N*2D][Cc], backward image A[Cc][N*2D]; -1 = per-block path
+  int64_t frag_condF = -1, frag_condB = -1;
+  int64_t frag16_skipF = -1;   // the same as an fp16 split image, or -1
+  int64_t frag_floats = 0;
+  // skip path folded into the head's first convolution (training passes; see wn_skip_fold_kernel): F0 = its width,
+  // forward image A[F0][N*D] of V^T.  prep2 = pieces whose SOURCE is the workspace (the V matrix), not the parameters
+  int fold_F0 = 0;
+  int64_t frag16_foldF = -1;
+  std::vector<WnPrepDesc> prep2;
+  WnPrepDesc* d_prep2 = nullptr;
+  WnTensorDesc* d_cov_fold = nullptr;
+  WnTensorDesc h_cov_fold = {0, 0};     // host copies of the coverage tables (the flattened reduce sizes its grid from them)
+  std::vector<WnPrepDesc> prep;
+  std::vector<WnTensorDesc> tdesc, kdesc;
+  // device copies (lazy)
+  WnPrepDesc* d_prep = nullptr;
+  WnTensorDesc* d_tdesc = nullptr;
+  WnTensorDesc* d_kdesc = nullptr;
+  bool fused_ok = false, fused16_ok = false;
+  bool deep16_ok = false;      // layers_per_block > 1: split-precision images of the whole stack exist
+  // device copies of the immutable tables above are made on first use (a plan can be created without a GPU): guarded
+  // by tables_once, never changed afterwards
+  std::mutex tables_mu;
+  bool tables_ready = false;
+  // Everything that CHANGES while a plan is used lives in a wn_exec (below).  `own` is the execution state of callers that
+  // never bind one of their own (wn_exec_bind): created with the plan, destroyed with it.
+  struct wn_exec* own = nullptr;
+};
+
 namespace wnp {
+// the execution state of the calling thread for this plan: the bound one if it belongs to the plan, else the plan's own
+wn_exec& ex(const wn_plan* p);
+void exec_release(wn_exec* e);
+
 
 struct Carver {
   int64_t pos = 0;

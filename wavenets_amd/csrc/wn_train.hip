@@ -46,9 +46,9 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
   const bool headpairs = head_pairs_ok(p) && L.hsplits > 0;
   const bool inconvk = L.isplits > 0;
   const bool d16 = deep16(p);
-  if (p->d_jobs && p->jobs_B == B && p->jobs_T == T && p->jobs_splits == L.bsplits &&
-      p->jobs_drop == (p->drop_rate > 0.f) && p->jobs_skipk == skipk && p->jobs_layerk == layerk &&
-      p->jobs_pairk == pairk && p->jobs_mfused == mfused && p->jobs_mtr == mtr && p->jobs_deep16 == d16 && p->jobs_headpairs == headpairs && p->jobs_inconvk == inconvk && p->jobs_fold == fold) return WN_OK;
+  if (wnp::ex(p).d_jobs && wnp::ex(p).jobs_B == B && wnp::ex(p).jobs_T == T && wnp::ex(p).jobs_splits == L.bsplits &&
+      wnp::ex(p).jobs_drop == (wnp::ex(p).drop_rate > 0.f) && wnp::ex(p).jobs_skipk == skipk && wnp::ex(p).jobs_layerk == layerk &&
+      wnp::ex(p).jobs_pairk == pairk && wnp::ex(p).jobs_mfused == mfused && wnp::ex(p).jobs_mtr == mtr && wnp::ex(p).jobs_deep16 == d16 && wnp::ex(p).jobs_headpairs == headpairs && wnp::ex(p).jobs_inconvk == inconvk && wnp::ex(p).jobs_fold == fold) return WN_OK;
   std::vector<WnWgLayer> wgl, wgli;
   std::vector<WnWgPair> pairs[3];
   std::vector<WnWgPair> hpairs[6];
@@ -73,7 +73,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     const ConvInfo& c = bi.dil.back();
     const int64_t zoff = L.Z + (int64_t)b * B * T * p->Dp;      // block-major Z
     if (layerk) {
-      const int64_t xin0 = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
+      const int64_t xin0 = wnp::ex(p).drop_rate > 0.f ? L.XD[b] : L.H[b];
       for (int i = 0; i + 1 < p->LPB; ++i) {                     // inner convs of a deeper stack
         const ConvInfo& ci = bi.dil[i];
         WnWgLayer w;
@@ -97,7 +97,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       w.dilation = c.dil;
       wgl.push_back(w);
     } else if (pairk) {
-      const int64_t xoff = p->drop_rate > 0.f ? L.XD[b] : L.H[b];
+      const int64_t xoff = wnp::ex(p).drop_rate > 0.f ? L.XD[b] : L.H[b];
       {
         // both taps in one job: x[t - d] | x[t] against ONE read of du
         WnWgPair w;
@@ -128,7 +128,7 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     for (int i = 0; i < p->LPB; ++i) {
       const ConvInfo& ci = bi.dil[i];
       const bool lastc = i == p->LPB - 1;
-      const int64_t xo = i == 0 ? (p->drop_rate > 0.f ? L.XD[b] : L.H[b]) : L.P[b][i - 1];
+      const int64_t xo = i == 0 ? (wnp::ex(p).drop_rate > 0.f ? L.XD[b] : L.H[b]) : L.P[b][i - 1];
       const int kc = i == 0 ? p->R : p->D, nc = lastc ? 2 * p->D : p->D;
       for (int t = 0; t < p->KS; ++t)
         add_jobs(jobs, xo, kc, kc, (p->KS - 1 - t) * ci.dil, lastc ? L.GU[b] : L.GP[b][i], nc, nc,
@@ -165,8 +165,8 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
       pairs[0].push_back(w);
     }
   }
-  p->head_first = (int)jobs.size();
-  p->cov_head_first = (int)cov.size();
+  wnp::ex(p).head_first = (int)jobs.size();
+  wnp::ex(p).cov_head_first = (int)cov.size();
   for (size_t i = fold ? 1 : 0; i < p->finals.size(); ++i) {      // (folded: the first conv's gradients come from M too)
     const ConvInfo& c = p->finals[i];
     const int64_t xin = (i == 0) ? (p->c.use_skip ? L.skipsum : L.H[p->N]) : L.HA[i - 1];
@@ -188,47 +188,47 @@ int ensure_jobs(wn_plan* p, const WsLayout& L, int B, int T) {
     }
     cover(c.kernel_t); cover(c.bias_t);
   }
-  if (p->d_jobs) { (void)hipFree(p->d_jobs); p->d_jobs = nullptr; }
-  if (p->d_cov) { (void)hipFree(p->d_cov); p->d_cov = nullptr; }
-  WN_HIP_CHECK(hipMalloc((void**)&p->d_jobs, std::max<size_t>(jobs.size(), 1) * sizeof(WnWgJob)));
-  if (!jobs.empty()) WN_HIP_CHECK(hipMemcpy(p->d_jobs, jobs.data(), jobs.size() * sizeof(WnWgJob), hipMemcpyHostToDevice));
-  WN_HIP_CHECK(hipMalloc((void**)&p->d_cov, cov.size() * sizeof(WnTensorDesc)));
-  WN_HIP_CHECK(hipMemcpy(p->d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
-  p->h_cov = cov;
-  if (p->d_wgl) { (void)hipFree(p->d_wgl); p->d_wgl = nullptr; }
+  if (wnp::ex(p).d_jobs) { (void)hipFree(wnp::ex(p).d_jobs); wnp::ex(p).d_jobs = nullptr; }
+  if (wnp::ex(p).d_cov) { (void)hipFree(wnp::ex(p).d_cov); wnp::ex(p).d_cov = nullptr; }
+  WN_HIP_CHECK(hipMalloc((void**)&wnp::ex(p).d_jobs, std::max<size_t>(jobs.size(), 1) * sizeof(WnWgJob)));
+  if (!jobs.empty()) WN_HIP_CHECK(hipMemcpy(wnp::ex(p).d_jobs, jobs.data(), jobs.size() * sizeof(WnWgJob), hipMemcpyHostToDevice));
+  WN_HIP_CHECK(hipMalloc((void**)&wnp::ex(p).d_cov, cov.size() * sizeof(WnTensorDesc)));
+  WN_HIP_CHECK(hipMemcpy(wnp::ex(p).d_cov, cov.data(), cov.size() * sizeof(WnTensorDesc), hipMemcpyHostToDevice));
+  wnp::ex(p).h_cov = cov;
+  if (wnp::ex(p).d_wgl) { (void)hipFree(wnp::ex(p).d_wgl); wnp::ex(p).d_wgl = nullptr; }
   if (!wgl.empty()) {
-    WN_HIP_CHECK(hipMalloc((void**)&p->d_wgl, wgl.size() * sizeof(WnWgLayer)));
-    WN_HIP_CHECK(hipMemcpy(p->d_wgl, wgl.data(), wgl.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
+    WN_HIP_CHECK(hipMalloc((void**)&wnp::ex(p).d_wgl, wgl.size() * sizeof(WnWgLayer)));
+    WN_HIP_CHECK(hipMemcpy(wnp::ex(p).d_wgl, wgl.data(), wgl.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
   }
-  if (p->d_wgli) { (void)hipFree(p->d_wgli); p->d_wgli = nullptr; }
-  p->n_wgli = (int)wgli.size();
+  if (wnp::ex(p).d_wgli) { (void)hipFree(wnp::ex(p).d_wgli); wnp::ex(p).d_wgli = nullptr; }
+  wnp::ex(p).n_wgli = (int)wgli.size();
   if (!wgli.empty()) {
-    WN_HIP_CHECK(hipMalloc((void**)&p->d_wgli, wgli.size() * sizeof(WnWgLayer)));
-    WN_HIP_CHECK(hipMemcpy(p->d_wgli, wgli.data(), wgli.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
+    WN_HIP_CHECK(hipMalloc((void**)&wnp::ex(p).d_wgli, wgli.size() * sizeof(WnWgLayer)));
+    WN_HIP_CHECK(hipMemcpy(wnp::ex(p).d_wgli, wgli.data(), wgli.size() * sizeof(WnWgLayer), hipMemcpyHostToDevice));
   }
-  if (p->d_pairs) { (void)hipFree(p->d_pairs); p->d_pairs = nullptr; }
+  if (wnp::ex(p).d_pairs) { (void)hipFree(wnp::ex(p).d_pairs); wnp::ex(p).d_pairs = nullptr; }
   {
     std::vector<WnWgPair> all;
     for (int kd = 0; kd <= 2; ++kd) {
-      p->pair_first[kd] = (int)all.size();
-      p->pair_count[kd] = (int)pairs[kd].size();
+      wnp::ex(p).pair_first[kd] = (int)all.size();
+      wnp::ex(p).pair_count[kd] = (int)pairs[kd].size();
       all.insert(all.end(), pairs[kd].begin(), pairs[kd].end());
     }
     for (int kd = 1; kd <= 5; ++kd) {
-      p->hpair_first[kd] = (int)all.size();
-      p->hpair_count[kd] = (int)hpairs[kd].size();
+      wnp::ex(p).hpair_first[kd] = (int)all.size();
+      wnp::ex(p).hpair_count[kd] = (int)hpairs[kd].size();
       all.insert(all.end(), hpairs[kd].begin(), hpairs[kd].end());
     }
     if (!all.empty()) {
-      WN_HIP_CHECK(hipMalloc((void**)&p->d_pairs, all.size() * sizeof(WnWgPair)));
-      WN_HIP_CHECK(hipMemcpy(p->d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
+      WN_HIP_CHECK(hipMalloc((void**)&wnp::ex(p).d_pairs, all.size() * sizeof(WnWgPair)));
+      WN_HIP_CHECK(hipMemcpy(wnp::ex(p).d_pairs, all.data(), all.size() * sizeof(WnWgPair), hipMemcpyHostToDevice));
     }
   }
-  p->jobs_layerk = layerk; p->jobs_pairk = pairk; p->jobs_mfused = mfused; p->jobs_mtr = mtr; p->jobs_deep16 = d16; p->jobs_headpairs = headpairs; p->jobs_inconvk = inconvk;
-  p->jobs_fold = fold;
-  p->njobs = (int)jobs.size(); p->ncov = (int)cov.size();
-  p->jobs_B = B; p->jobs_T = T; p->jobs_splits = L.bsplits; p->jobs_drop = p->drop_rate > 0.f;
-  p->jobs_skipk = skipk;
+  wnp::ex(p).jobs_layerk = layerk; wnp::ex(p).jobs_pairk = pairk; wnp::ex(p).jobs_mfused = mfused; wnp::ex(p).jobs_mtr = mtr; wnp::ex(p).jobs_deep16 = d16; wnp::ex(p).jobs_headpairs = headpairs; wnp::ex(p).jobs_inconvk = inconvk;
+  wnp::ex(p).jobs_fold = fold;
+  wnp::ex(p).njobs = (int)jobs.size(); wnp::ex(p).ncov = (int)cov.size();
+  wnp::ex(p).jobs_B = B; wnp::ex(p).jobs_T = T; wnp::ex(p).jobs_splits = L.bsplits; wnp::ex(p).jobs_drop = wnp::ex(p).drop_rate > 0.f;
+  wnp::ex(p).jobs_skipk = skipk;
   return WN_OK;
 }
 
@@ -257,7 +257,7 @@ struct TrainCall {
   int forward_and_loss() {
     int rc;
     { const int rcs = shift_split(x_full, B, T, inputs, ws + L.yt, s); if (rcs) return rcs; }
-    if (p->phase_on) (void)hipEventRecord(p->phase_ev[0], s);
+    if (wnp::ex(p).phase_on) (void)hipEventRecord(wnp::ex(p).phase_ev[0], s);
     // (zeroed before the forward pass: a fused loss epilogue publishes the max-abs of d loss / d logits from there)
     WN_HIP_CHECK(hipMemsetAsync(am, 0, L.n_absmax * sizeof(float), s));
     // 256-class categorical head: the loss rides in the head's last conv (LossFuse) unless the caller wants the probabilities
@@ -270,15 +270,15 @@ struct TrainCall {
       lf.target = reinterpret_cast<const int32_t*>(ws + L.target);
       lf.gscale = 1.0f / (float)global_batch;          // compute_average_loss, src/model.py:328-329
       lf.loss_rows = ws + L.loss_rows; lf.g_logits = ws + L.GF.back(); lf.absmax_out = am_GF(nf - 1);
-      if (p->step_sample && !p->step_sample_det) {     // the armed sample_waveform(pred) draw of the step (src/model.py:338)
-        lf.sample_out = p->step_sample; lf.inv_lv = 1.0f / (float)(1 << (p->c.bits - 1));
-        lf.seed = p->step_sample_seed; lf.offset = p->step_sample_off;
+      if (wnp::ex(p).step_sample && !wnp::ex(p).step_sample_det) {     // the armed sample_waveform(pred) draw of the step (src/model.py:338)
+        lf.sample_out = wnp::ex(p).step_sample; lf.inv_lv = 1.0f / (float)(1 << (p->c.bits - 1));
+        lf.seed = wnp::ex(p).step_sample_seed; lf.offset = wnp::ex(p).step_sample_off;
       }
     }
     rc = forward_core(p, params, inputs, true, cond, B, T, true, ws, L, s, nullptr, fuse ? &lf : nullptr);
     if (rc) return rc;
-    if (lf.done && lf.sample_out) p->step_sample = nullptr;     // drawn
-    if (p->phase_on) (void)hipEventRecord(p->phase_ev[1], s);
+    if (lf.done && lf.sample_out) wnp::ex(p).step_sample = nullptr;     // drawn
+    if (wnp::ex(p).phase_on) (void)hipEventRecord(wnp::ex(p).phase_ev[1], s);
     rc = loss_stage(p, B, T, global_batch, true, ws, L, loss_out, am_GF(nf - 1), s, lf.done);
     if (rc) return rc;
     if (pred_out) {
@@ -286,21 +286,21 @@ struct TrainCall {
       else rc = hipMemcpyAsync(pred_out, ws + L.logits, rows * p->Cout * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? WN_OK : WN_E_HIP;
       if (rc) return rc;
     }
-    if (p->step_sample) {
+    if (wnp::ex(p).step_sample) {
       // sample_waveform(pred) of this step (src/model.py:338) drawn from the logits while they are still hot:
       // no (rows, C) probability tensor is written or re-read
-      float* so = p->step_sample;
-      p->step_sample = nullptr;
+      float* so = wnp::ex(p).step_sample;
+      wnp::ex(p).step_sample = nullptr;
       if (p->c.head == WN_HEAD_CATEGORICAL) {
-        if (p->step_sample_det) {
+        if (wnp::ex(p).step_sample_det) {
           wn_set_error("step sample: deterministic categorical draws go through wn_sample_waveform");
           return WN_E_UNSUPPORTED;
         }
-        rc = wn_launch_sample_rand_cat_logits(ws + L.logits, rows, p->Cout, p->c.bits, p->step_sample_seed, p->step_sample_off, so, s);
+        rc = wn_launch_sample_rand_cat_logits(ws + L.logits, rows, p->Cout, p->c.bits, wnp::ex(p).step_sample_seed, wnp::ex(p).step_sample_off, so, s);
       } else {
         // mixture heads: the model output IS the logits tensor
-        if (p->step_sample_det) rc = wn_launch_sample_det(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, so, s);
-        else rc = wn_launch_sample_rand(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, p->step_sample_seed, p->step_sample_off, so, s);
+        if (wnp::ex(p).step_sample_det) rc = wn_launch_sample_det(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, so, s);
+        else rc = wn_launch_sample_rand(ws + L.logits, rows, p->Cout, p->c.num_mixtures, p->c.bits, p->c.head, wnp::ex(p).step_sample_seed, wnp::ex(p).step_sample_off, so, s);
       }
       if (rc) return rc;
     }
@@ -317,10 +317,10 @@ struct TrainCall {
       if (rc) return rc;
     }
     // (with dropout the split kernels read H * mask / (1 - rate) while only H is published: compare against limit * (1 - rate))
-    rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT * (p->drop_rate > 0.f ? 1.f - p->drop_rate : 1.f),
+    rc = wn_launch_guard_flag(ws + L.fwd_absmax, WN_RANGE_LIMIT * (wnp::ex(p).drop_rate > 0.f ? 1.f - wnp::ex(p).drop_rate : 1.f),
                               wn_debug_get(1) != 1, loss_out + 2, s);
     if (rc) return rc;
-    if (p->phase_on) (void)hipEventRecord(p->phase_ev[2], s);
+    if (wnp::ex(p).phase_on) (void)hipEventRecord(wnp::ex(p).phase_ev[2], s);
     return WN_OK;
   }
 
@@ -378,7 +378,7 @@ struct TrainCall {
     }
     // Two products per launch (wn_bwd_pair.hip): g_x(b+1) and, from it in registers, g_u(b).  The chain is then
     //   g_u(N-1) | { g_x(b+1), g_u(b) } for b = N-2 .. 0 | g_x(0)   = N + 1 launches instead of 2 N.
-    const bool pairk = fold && p->N >= 2 && p->drop_rate == 0.f && p->c.use_residual && (p->c.cond_inputs == 0 || cond_batched) &&
+    const bool pairk = fold && p->N >= 2 && wnp::ex(p).drop_rate == 0.f && p->c.use_residual && (p->c.cond_inputs == 0 || cond_batched) &&
                        (wn_bwd_pair_supported(p->R, p->D, p->KS, p->fold_F0) || wn_bwd_s128_supported(p->R, p->D, p->KS, p->fold_F0)) &&
                        p->Dp == p->D &&
                        // (the streamed R = 128 pair kernel indexes with 32-bit byte offsets: the two-launch chain takes over beyond)
@@ -414,7 +414,7 @@ struct TrainCall {
       }
       BlockBufs f;
       memset(&f, 0, sizeof(f));
-      f.x = (p->drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
+      f.x = (wnp::ex(p).drop_rate > 0.f) ? ws + L.XD[b] : ws + L.H[b];
       for (int i = 0; i + 1 < p->LPB; ++i) f.P[i] = ws + L.P[b][i];
       f.AG = ws + L.AG[b];
       f.Z = ws + L.Z + (int64_t)b * rows * p->Dp; f.ldz = p->Dp;
@@ -424,8 +424,8 @@ struct TrainCall {
       for (int i = 0; i + 1 < p->LPB; ++i) bg.g_pi[i] = ws + L.GP[b][i];
       if (deep16(p))
         for (int i = 0; i + 1 < p->LPB; ++i) bg.am_gp[i] = am_GP(b, i);
-      if (p->drop_rate > 0.f) {
-        bg.drop_rate = p->drop_rate; bg.drop_key = wn_dropout_key(p->drop_seed, b, p->drop_step); bg.g_xd = ws + L.gxd;
+      if (wnp::ex(p).drop_rate > 0.f) {
+        bg.drop_rate = wnp::ex(p).drop_rate; bg.drop_key = wn_dropout_key(wnp::ex(p).drop_seed, b, wnp::ex(p).drop_step); bg.g_xd = ws + L.gxd;
       }
       // the last block's output gradient is identically zero when the head reads the skip sum
       // (with the skip head nothing flows into the last block's output: GH[N] was zero-filled above.  It is
@@ -463,10 +463,10 @@ struct TrainCall {
     // M = Z^T dL/da (N*D x F0) and colsum(dL/da) into their own slab, reduced, then the three small products
     const int F0 = p->fold_F0;
     const int64_t pm = (int64_t)p->N * p->D * F0 + F0;
-    if (p->jobs_mtr != 0)
-      rc = wn_launch_wgrad_tr(p->jobs_mtr, p->d_pairs + p->pair_first[0], p->pair_count[0], ws, ws + L.mslab, pm, B, T,
+    if (wnp::ex(p).jobs_mtr != 0)
+      rc = wn_launch_wgrad_tr(wnp::ex(p).jobs_mtr, wnp::ex(p).d_pairs + wnp::ex(p).pair_first[0], wnp::ex(p).pair_count[0], ws, ws + L.mslab, pm, B, T,
                               L.bsplits, s);
-    else if (!p->jobs_mfused)
+    else if (!wnp::ex(p).jobs_mfused)
     rc = wn_launch_wgrad_skip(ws + L.Z, p->Dp, ws + L.GF[0], F0, rows, p->N * p->D, F0, p->D, B * L.bsplits, ws + L.mslab, pm,
                               0, (int64_t)p->D * F0, (int64_t)p->N * p->D * F0, 0, 1, am_GF(0), s);
     if (rc) return rc;
@@ -535,15 +535,15 @@ struct TrainCall {
   //      conv, head) beside them on a side stream, then the slab reductions into the flat gradient ----
   int weight_gradients() {
     int rc;
-    if (p->phase_on) (void)hipEventRecord(p->phase_ev[3], s);      // backward-data chain done
+    if (wnp::ex(p).phase_on) (void)hipEventRecord(wnp::ex(p).phase_ev[3], s);      // backward-data chain done
     // the generic jobs left over (input conv, head) are few single-wave jobs: they run beside the
     // per-block and skip kernels on a side stream (disjoint slab regions), joined before the reduce.
     // knob 9 = 1 keeps everything on the caller's stream (A/B of the overlap).
-    const bool fork = (p->jobs_layerk || p->jobs_pairk) && wn_debug_get(9) != 1;
-    if (fork && !p->side) {
-      WN_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-      WN_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-      WN_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    const bool fork = (wnp::ex(p).jobs_layerk || wnp::ex(p).jobs_pairk) && wn_debug_get(9) != 1;
+    if (fork && !wnp::ex(p).side) {
+      WN_HIP_CHECK(hipStreamCreateWithFlags(&wnp::ex(p).side, hipStreamNonBlocking));
+      WN_HIP_CHECK(hipEventCreateWithFlags(&wnp::ex(p).ev_fork, hipEventDisableTiming));
+      WN_HIP_CHECK(hipEventCreateWithFlags(&wnp::ex(p).ev_join, hipEventDisableTiming));
     }
     // Whatever happens after the fork, the caller's stream must not run ahead of the side stream's kernels (they
     // read and write the workspace and the gradient slab): an early error return joins through this guard.
@@ -551,65 +551,65 @@ struct TrainCall {
       wn_plan* p; hipStream_t s; bool armed;
       ~SideJoin() {
         if (!armed) return;
-        if (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)
-          (void)hipStreamSynchronize(p->side);
+        if (hipEventRecord(wnp::ex(p).ev_join, wnp::ex(p).side) != hipSuccess || hipStreamWaitEvent(s, wnp::ex(p).ev_join, 0) != hipSuccess)
+          (void)hipStreamSynchronize(wnp::ex(p).side);
       }
     } side_join{p, s, false};
     if (fork) {
-      WN_HIP_CHECK(hipEventRecord(p->ev_fork, s));
-      WN_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+      WN_HIP_CHECK(hipEventRecord(wnp::ex(p).ev_fork, s));
+      WN_HIP_CHECK(hipStreamWaitEvent(wnp::ex(p).side, wnp::ex(p).ev_fork, 0));
       side_join.armed = true;
     }
-    if (p->jobs_inconvk) {
+    if (wnp::ex(p).jobs_inconvk) {
       rc = wn_launch_inconv_wgrad(inputs, ws + L.GH[0], B, T, p->R, p->KS, L.isplits, ws + L.islab, (int64_t)(p->KS + 1) * p->R,
-                                  0, (int64_t)p->KS * p->R, fork ? p->side : s);
+                                  0, (int64_t)p->KS * p->R, fork ? wnp::ex(p).side : s);
       if (rc) return rc;
     }
-    const bool head_own = L.hsplits > 0 && (p->head_first < p->njobs || p->jobs_headpairs);
-    rc = wn_launch_wgrad_batched(p->d_jobs, head_own ? p->head_first : p->njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits,
-                                 fork ? p->side : s, p->LPB > 1 && !p->jobs_deep16);
+    const bool head_own = L.hsplits > 0 && (wnp::ex(p).head_first < wnp::ex(p).njobs || wnp::ex(p).jobs_headpairs);
+    rc = wn_launch_wgrad_batched(wnp::ex(p).d_jobs, head_own ? wnp::ex(p).head_first : wnp::ex(p).njobs, ws, ws + L.bslab, p->nparams, B, T, L.bsplits,
+                                 fork ? wnp::ex(p).side : s, p->LPB > 1 && !wnp::ex(p).jobs_deep16);
     if (rc) return rc;
     if (head_own) {
       // job and coverage offsets are offsets into the flat parameter buffer: the compact slab is addressed
       // through a base shifted by -head_base with the head span as its row pitch
-      if (p->head_first < p->njobs) {
-        rc = wn_launch_wgrad_batched(p->d_jobs + p->head_first, p->njobs - p->head_first, ws, ws + L.hslab - L.head_base,
-                                     L.head_span, B, T, L.hsplits, fork ? p->side : s);
+      if (wnp::ex(p).head_first < wnp::ex(p).njobs) {
+        rc = wn_launch_wgrad_batched(wnp::ex(p).d_jobs + wnp::ex(p).head_first, wnp::ex(p).njobs - wnp::ex(p).head_first, ws, ws + L.hslab - L.head_base,
+                                     L.head_span, B, T, L.hsplits, fork ? wnp::ex(p).side : s);
         if (rc) return rc;
       }
-      if (p->jobs_headpairs)
+      if (wnp::ex(p).jobs_headpairs)
         for (int kd = 1; kd <= 5; ++kd)
-          if (p->hpair_count[kd] > 0) {
+          if (wnp::ex(p).hpair_count[kd] > 0) {
             // staged kinds 1 (128 x 256), 3 (256 x 128), 5 (256 x 256 halves) have transposed-read forms (3, 4, 5)
             const int trk = kd == 1 ? 3 : (kd == 3 ? 4 : (kd == 5 ? 5 : (kd == 2 ? 2 : 0)));
-            if (trk != 0 && p->jobs_pairk)                 // (with 64-channel blocks the staged head jobs are faster beside the side stream's neighbours)
-              rc = wn_launch_wgrad_tr(trk, p->d_pairs + p->hpair_first[kd], p->hpair_count[kd], ws, ws + L.hslab - L.head_base,
-                                      L.head_span, B, T, L.hsplits, fork ? p->side : s);
+            if (trk != 0 && wnp::ex(p).jobs_pairk)                 // (with 64-channel blocks the staged head jobs are faster beside the side stream's neighbours)
+              rc = wn_launch_wgrad_tr(trk, wnp::ex(p).d_pairs + wnp::ex(p).hpair_first[kd], wnp::ex(p).hpair_count[kd], ws, ws + L.hslab - L.head_base,
+                                      L.head_span, B, T, L.hsplits, fork ? wnp::ex(p).side : s);
             else
-            rc = wn_launch_wgrad_pairs(kd, p->d_pairs + p->hpair_first[kd], p->hpair_count[kd], ws, ws + L.hslab - L.head_base,
-                                       L.head_span, B, T, L.hsplits, fork ? p->side : s);
+            rc = wn_launch_wgrad_pairs(kd, wnp::ex(p).d_pairs + wnp::ex(p).hpair_first[kd], wnp::ex(p).hpair_count[kd], ws, ws + L.hslab - L.head_base,
+                                       L.head_span, B, T, L.hsplits, fork ? wnp::ex(p).side : s);
             if (rc) return rc;
           }
     }
-    if (fork) WN_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
+    if (fork) WN_HIP_CHECK(hipEventRecord(wnp::ex(p).ev_join, wnp::ex(p).side));
     for (int kd = 1; kd <= 2; ++kd)
-      if (p->jobs_pairk && p->pair_count[kd] > 0) {
+      if (wnp::ex(p).jobs_pairk && wnp::ex(p).pair_count[kd] > 0) {
         // transposed-read kernels: both taps of dW_d in one job; dW_r (+ M)
-        rc = wn_launch_wgrad_tr(kd == 2 && p->jobs_mfused ? 6 : kd, p->d_pairs + p->pair_first[kd], p->pair_count[kd], ws,
+        rc = wn_launch_wgrad_tr(kd == 2 && wnp::ex(p).jobs_mfused ? 6 : kd, wnp::ex(p).d_pairs + wnp::ex(p).pair_first[kd], wnp::ex(p).pair_count[kd], ws,
                                 ws + L.bslab, p->nparams, B, T, L.bsplits, s, ws + L.mslab,
                                 (int64_t)p->N * p->D * p->fold_F0 + p->fold_F0);
         if (rc) return rc;
       }
-    if (p->jobs_layerk) {
-      rc = wn_launch_wgrad_layers(p->d_wgl, p->N, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
+    if (wnp::ex(p).jobs_layerk) {
+      rc = wn_launch_wgrad_layers(wnp::ex(p).d_wgl, p->N, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s);
       if (rc) return rc;
-      rc = wn_launch_wgrad_layers(p->d_wgli, p->n_wgli, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s, 1);
+      rc = wn_launch_wgrad_layers(wnp::ex(p).d_wgli, wnp::ex(p).n_wgli, p->R, ws, ws + L.bslab, p->nparams, B, T, L.bsplits, s, 1);
       if (rc) return rc;
     }
     if (fold) {
       rc = fold_weight_gradients();
       if (rc) return rc;
-    } else if (p->jobs_skipk) {
+    } else if (wnp::ex(p).jobs_skipk) {
       const BlockInfo& b0 = p->blocks[0];
       const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
       const int64_t bst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.bias_t].off - p->tensors[b0.conv_skip.bias_t].off : 0;
@@ -618,23 +618,23 @@ struct TrainCall {
                                 p->tensors[b0.conv_skip.bias_t].off, bst, p->N, am_gskip, s);
       if (rc) return rc;
     }
-    if (fork) { WN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0)); side_join.armed = false; }
+    if (fork) { WN_HIP_CHECK(hipStreamWaitEvent(s, wnp::ex(p).ev_join, 0)); side_join.armed = false; }
     if (cond_batched) {
       rc = cond_weight_gradients();
       if (rc) return rc;
     }
     // coverage entries 0, 1 are the input conv's kernel and bias: from their compact slab when the dedicated kernel ran
-    const int cov0 = p->jobs_inconvk ? 2 : 0;
-    rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, p->d_cov + cov0,
-                                (head_own ? p->cov_head_first : p->ncov) - cov0, s, p->h_cov.data() + cov0);
+    const int cov0 = wnp::ex(p).jobs_inconvk ? 2 : 0;
+    rc = wn_launch_reduce_table(ws + L.bslab, B * L.bsplits, p->nparams, grads, wnp::ex(p).d_cov + cov0,
+                                (head_own ? wnp::ex(p).cov_head_first : wnp::ex(p).ncov) - cov0, s, wnp::ex(p).h_cov.data() + cov0);
     if (rc) return rc;
-    if (p->jobs_inconvk) {
-      rc = wn_launch_reduce_table(ws + L.islab, B * L.isplits, (int64_t)(p->KS + 1) * p->R, grads, p->d_cov, 2, s, p->h_cov.data());
+    if (wnp::ex(p).jobs_inconvk) {
+      rc = wn_launch_reduce_table(ws + L.islab, B * L.isplits, (int64_t)(p->KS + 1) * p->R, grads, wnp::ex(p).d_cov, 2, s, wnp::ex(p).h_cov.data());
       if (rc) return rc;
     }
     if (head_own) {
-      rc = wn_launch_reduce_table(ws + L.hslab - L.head_base, B * L.hsplits, L.head_span, grads, p->d_cov + p->cov_head_first,
-                                  p->ncov - p->cov_head_first, s, p->h_cov.data() + p->cov_head_first);
+      rc = wn_launch_reduce_table(ws + L.hslab - L.head_base, B * L.hsplits, L.head_span, grads, wnp::ex(p).d_cov + wnp::ex(p).cov_head_first,
+                                  wnp::ex(p).ncov - wnp::ex(p).cov_head_first, s, wnp::ex(p).h_cov.data() + wnp::ex(p).cov_head_first);
       if (rc) return rc;
     }
     if (!p->c.use_skip && p->S > 0) {
@@ -713,8 +713,8 @@ struct TrainCall {
       rc = wn_launch_axpy_table(grads, params, p->d_kdesc, (int)p->kdesc.size(), 2.0f * p->c.l2_reg_factor / (float)n_replicas, s);
       if (rc) return rc;
     }
-    if (p->phase_on) {
-      (void)hipEventRecord(p->phase_ev[4], s);
+    if (wnp::ex(p).phase_on) {
+      (void)hipEventRecord(wnp::ex(p).phase_ev[4], s);
     }
 
     return WN_OK;
@@ -725,7 +725,7 @@ struct TrainCall {
 
 extern "C" int wn_plan_set_train_phases(wn_plan* p, int32_t phases) {
   if (!p || phases < 1 || phases > 3) { wn_set_error("set_train_phases: 1 (forward + loss), 2 (backward), 3 (both)"); return WN_E_INVALID; }
-  p->train_phases = phases;
+  wnp::ex(p).train_phases = phases;
   return WN_OK;
 }
 
@@ -749,7 +749,7 @@ extern "C" int wn_train_fwd_bwd(wn_plan* p, const float* params, const float* x_
   // A caller may run the step as two calls (wn_plan_set_train_phases 1, then 2) and queue work of its own in between --
   // the Python mirror reads the loss and the metrics back from there, 4 ms before the step ends.  Everything the second
   // half needs lives in the workspace.
-  const int phases = p->train_phases;
+  const int phases = wnp::ex(p).train_phases;
   int rc = WN_OK;
   if (phases & 1) rc = c.forward_and_loss();
   if (!rc && (phases & 2)) rc = c.backward();
