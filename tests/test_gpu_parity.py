@@ -1038,6 +1038,26 @@ def test_queued_generation_mixture_head_in_one_launch(channels, sampler, mix, fi
   assert torch.equal(naive, queued), (naive - queued).abs().max()
 
 
+def test_generation_relay_watchdog_reports_a_missing_hand_over():
+  """Every wait of the relay is bounded: when a block never hands its rows on (fault injection, knob 3), its successor
+  gives up after 2^21 polls (a fraction of a second), records itself in the watchdog word behind the guard slot, the launch ENDS, and
+  WaveNet.generate raises instead of returning the samples; the next call on the same workspace is good again."""
+  from wavenets_amd import _lib
+  kw = dict(blocks=6, channels=128, skip_channels=256, dilation_bound=16, final_layers_channels=[128, 64],
+            activation='leaky_relu', bits=8)
+  ocfg, params, model = make_pair(seed=17, bias_range=0.3, **kw)
+  w = O.synthetic_waveform(3, model.receptive_field, seed=3).to(dev())
+  good = model.generate(6, sample=w, use_queues=True, deterministic=True)
+  _lib.lib().wn_debug_set(3, 3)                     # block 2 withholds its rows
+  try:
+    with pytest.raises(RuntimeError, match='gave up waiting'):
+      model.generate(3, sample=w, use_queues=True, deterministic=True)
+  finally:
+    _lib.lib().wn_debug_set(3, 0)
+  again = model.generate(6, sample=w, use_queues=True, deterministic=True)
+  assert torch.equal(good, again)
+
+
 def test_generation_relay_under_load_and_long_runs():
   """The relay's hand-offs with the GPU busy on another stream (a large copy kernel loop competing for the CUs and the
   fabric) and over many steps: 600 samples at 30 blocks of 128 channels, bit-identical to the one-workgroup form."""

@@ -16,6 +16,8 @@ extern "C" const char* wn_last_error_string(void) { return g_wn_err; }
 //            in, and the second arithmetic every parity test runs
 //    2  = 1: queued generation of 128-channel blocks in ONE workgroup per utterance tile (wn_gen_chain128_kernel) instead
 //            of the relay over one workgroup per block (wn_gen_relay128_kernel): the cross-check of the relay's hand-offs
+//    3  = b + 1: fault injection for the relay's watchdog: block b withholds its hand-over, its successor gives up after
+//            its bounded wait and wn_generate's watchdog word reports it (tests only)
 //    9  = 1: no side stream in the weight-gradient phase (everything on the caller's stream)
 //   24  = 1: the generation chain kernel stamps its phases with s_memtime for blocks 8..11 (wn_debug_gen_ts reads them)
 //   29  > 0: timing ablations of the 128-channel block forward; only in -DWN_S128_DIAG builds (tools/time_s128.py)

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void wn_gen_chain128_kernel(WnGen128Args a)
 // the launch ends in any case.
 typedef __attribute__((address_space(1))) unsigned long long wn_gu64;
 #define WN_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define WN_RELAY_SPINS (1u << 18)
+#define WN_RELAY_SPINS (1u << 21)
 
 namespace {
 
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
         if (rok) wmax = wn_absmax_acc(wmax, rv.x, rv.y, rv.z, rv.w);
         ov[rq].x += rv.x; ov[rq].y += rv.y; ov[rq].z += rv.z; ov[rq].w += rv.w;
       }
-      if (xgn && rok) {
+      if (xgn && rok && b != a.mute_block) {
         granule2_store(xnrs, (unsigned)(piece - 1024) * 32u, epoch, ov[rq].x, ov[rq].y);
         granule2_store(xnrs, (unsigned)(piece - 1024) * 32u + 16u, epoch, ov[rq].z, ov[rq].w);
       }
@@ -790,6 +790,7 @@ extern "C" int wn_debug_relay_ts(unsigned long long* out, int nblocks) {
 int wn_launch_gen_relay128(const WnGen128Args& a0, hipStream_t s) {
   WnGen128Args a = a0;
   a.ts = nullptr;
+  a.mute_block = wn_debug_get(3) - 1;                  // knob 3 = b + 1: block b withholds its rows (watchdog test)
   if (wn_debug_get(24) && a.nblocks <= 128) {
     if (!g_relay_ts) { (void)hipMalloc((void**)&g_relay_ts, 128 * 8 * 8); (void)hipMemset(g_relay_ts, 0, 128 * 8 * 8); }
     a.ts = g_relay_ts;

@@ -280,6 +280,7 @@ struct WnGen128Args {
   // the word a reader that gave up waiting writes
   int32_t ntiles; uint32_t epoch; int64_t relay_off; unsigned* tmo;
   unsigned long long* ts;          // phase stamps (knob 24) or null
+  int32_t mute_block;              // fault injection (knob 3): this block withholds its hand-over; -1 = none
 };
 int wn_launch_gen_chain128(const WnGen128Args& a, hipStream_t s);
 int wn_launch_gen_relay128(const WnGen128Args& a, hipStream_t s);
