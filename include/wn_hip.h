@@ -203,7 +203,10 @@ float wn_range_limit(void);
 /* ---- WaveNet.generate / _generation, src/model.py:241-307 (intended semantics) ----
  * window (B,RF,1) initial samples; out (B,length,1).  deterministic != 0: argmax / mode
  * sampling; else Philox draws keyed by seed.  queued != 0 uses per-layer ring buffers
- * (result-identical to the sliding window; the reference's README.md:16 TODO). */
+ * (result-identical to the sliding window; the reference's README.md:16 TODO).
+ * A queued step of 128-channel blocks is ONE launch of one workgroup per (block, 32 utterances) that hand their rows
+ * on inside the launch (wn_gen_relay128_kernel); it is taken while blocks x ceil(B / 32) fits the device's CU count,
+ * every wait in it is bounded, and a wait that gave up is reported through the word behind wn_generate_guard_slot. */
 int wn_generate(wn_plan* p, const float* params, const float* window, const float* cond, int32_t B,
                 int32_t length, int32_t deterministic, int32_t queued, uint64_t seed, float* out,
                 float* workspace, int64_t ws_floats, void* stream);
