@@ -86,32 +86,46 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
     rc = wn_launch_prep_table(p->d_prep, (int)p->prep.size(), params, fragbase, s);
     if (rc) return rc;
   }
-  const bool fp_prof = prep && fold_ok(p) && wnp::ex(p).foldprep_used + 2 <= (int)wnp::ex(p).foldprep_ev.size();
-  if (fp_prof) (void)hipEventRecord(wnp::ex(p).foldprep_ev[wnp::ex(p).foldprep_used], s);
-  // bias of the folded skip sum = sum over blocks of conv_skip (or conv1) biases
-  if (prep && p->c.use_skip) {
-    const ConvInfo& c0 = p->blocks[0].has_skip ? p->blocks[0].conv_skip : p->blocks[0].conv1;
-    WnVecSumArgs v;
-    v.base = params; v.off0 = p->tensors[c0.bias_t].off;
-    v.stride = p->N > 1 ? (p->tensors[(p->blocks[1].has_skip ? p->blocks[1].conv_skip : p->blocks[1].conv1).bias_t].off - v.off0) : 0;
-    v.count = p->N; v.len = p->Sh; v.out = ws + L.bias_sum;
-    rc = wn_launch_vecsum(v, s);
-    if (rc) return rc;
-  }
-  // (inference and the generation priming pass fold too: the queued sampler carries the folded contraction in its chain
-  // kernel and must reproduce the sliding window bit for bit)
+  // The weight-space preparation of the skip path (bias sum, V = W_s W_f0, its fp16 images: ~45 us of small launches) is
+  // only needed by the folded contraction at the END of the block chain.  With the side stream allowed (knob 9 = 0) it is
+  // forked off right where the stack begins (the stack's start event below) and runs beside the first blocks; the
+  // contraction waits for it.  Otherwise it runs here, on the caller's stream.
+  wn_exec& exs = wnp::ex(p);
   const bool fold = fold_ok(p);
-  if (fold && prep) {
-    const BlockInfo& b0 = p->blocks[0];
-    const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
-    rc = wn_launch_skip_fold(params, p->tensors[b0.conv_skip.kernel_t].off, wst, p->tensors[p->finals[0].kernel_t].off,
-                             p->tensors[p->finals[0].bias_t].off, ws + L.bias_sum, p->N, p->D, p->S, p->fold_F0, ws + L.vfold,
-                             ws + L.bfold, ws + L.wsall, s);
-    if (rc) return rc;
-    rc = wn_launch_prep_table(p->d_prep2, (int)p->prep2.size(), ws, fragbase, s, 64);  // sources relative to the workspace
+  const bool fork_prep = prep && fold && p->c.use_skip && wn_debug_get(9) == 0;
+  bool prep_forked = false;
+  auto fold_prep = [&](hipStream_t sp) -> int {
+    const bool fp_prof = prep && fold && exs.foldprep_used + 2 <= (int)exs.foldprep_ev.size();
+    if (fp_prof) (void)hipEventRecord(exs.foldprep_ev[exs.foldprep_used], sp);
+    // bias of the folded skip sum = sum over blocks of conv_skip (or conv1) biases
+    if (prep && p->c.use_skip) {
+      const ConvInfo& c0 = p->blocks[0].has_skip ? p->blocks[0].conv_skip : p->blocks[0].conv1;
+      WnVecSumArgs v;
+      v.base = params; v.off0 = p->tensors[c0.bias_t].off;
+      v.stride = p->N > 1 ? (p->tensors[(p->blocks[1].has_skip ? p->blocks[1].conv_skip : p->blocks[1].conv1).bias_t].off - v.off0) : 0;
+      v.count = p->N; v.len = p->Sh; v.out = ws + L.bias_sum;
+      const int r = wn_launch_vecsum(v, sp);
+      if (r) return r;
+    }
+    // (inference and the generation priming pass fold too: the queued sampler carries the folded contraction in its chain
+    // kernel and must reproduce the sliding window bit for bit)
+    if (fold && prep) {
+      const BlockInfo& b0 = p->blocks[0];
+      const int64_t wst = p->N > 1 ? p->tensors[p->blocks[1].conv_skip.kernel_t].off - p->tensors[b0.conv_skip.kernel_t].off : 0;
+      int r = wn_launch_skip_fold(params, p->tensors[b0.conv_skip.kernel_t].off, wst, p->tensors[p->finals[0].kernel_t].off,
+                                  p->tensors[p->finals[0].bias_t].off, ws + L.bias_sum, p->N, p->D, p->S, p->fold_F0, ws + L.vfold,
+                                  ws + L.bfold, ws + L.wsall, sp);
+      if (r) return r;
+      r = wn_launch_prep_table(p->d_prep2, (int)p->prep2.size(), ws, fragbase, sp, 64);  // sources relative to the workspace
+      if (r) return r;
+    }
+    if (fp_prof) { (void)hipEventRecord(exs.foldprep_ev[exs.foldprep_used + 1], sp); exs.foldprep_used += 2; }
+    return WN_OK;
+  };
+  if (!fork_prep) {
+    rc = fold_prep(s);
     if (rc) return rc;
   }
-  if (fp_prof) { (void)hipEventRecord(wnp::ex(p).foldprep_ev[wnp::ex(p).foldprep_used + 1], s); wnp::ex(p).foldprep_used += 2; }
   // conditioning: mapping Dense stack + per-block time-invariant bias  (src/model.py:221-225,
   // src/layers.py:203-204: conv_cond(repeat(m)) == per-utterance bias)
   const float* m = cond;
@@ -187,6 +201,24 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
                           !(training && wnp::ex(p).drop_rate > 0.f) && block_ptrs(p, 0, params, fragbase, B, T).fused;
   const bool stack_prof = !rings && wnp::ex(p).stack_used + 2 <= (int)wnp::ex(p).stack_ev.size();
   if (stack_prof) (void)hipEventRecord(wnp::ex(p).stack_ev[wnp::ex(p).stack_used], s);
+  if (fork_prep) {
+    // the stack's start event (above) is the fork point: whatever the preparation costs the chain shows inside the pair
+    if (!exs.side) {
+      WN_HIP_CHECK(hipStreamCreateWithFlags(&exs.side, hipStreamNonBlocking));
+      WN_HIP_CHECK(hipEventCreateWithFlags(&exs.ev_fork, hipEventDisableTiming));
+      WN_HIP_CHECK(hipEventCreateWithFlags(&exs.ev_join, hipEventDisableTiming));
+    }
+    if (!exs.ev_ffork) {
+      WN_HIP_CHECK(hipEventCreateWithFlags(&exs.ev_ffork, hipEventDisableTiming));
+      WN_HIP_CHECK(hipEventCreateWithFlags(&exs.ev_fjoin, hipEventDisableTiming));
+    }
+    WN_HIP_CHECK(hipEventRecord(exs.ev_ffork, s));     // behind whatever wrote the parameters
+    WN_HIP_CHECK(hipStreamWaitEvent(exs.side, exs.ev_ffork, 0));
+    rc = fold_prep(exs.side);
+    if (rc) return rc;
+    WN_HIP_CHECK(hipEventRecord(exs.ev_fjoin, exs.side));
+    prep_forked = true;
+  }
   for (int b = 0; b < p->N; ++b) {
     BlockPtrs k = block_ptrs(p, b, params, fragbase, B, T);
     if (training && !rings) deep16_ptrs(p, b, fragbase, k);
@@ -230,6 +262,7 @@ int forward_core(wn_plan* p, const float* params, const float* x, bool prep, con
         if (rc) return rc;
       }
   }
+  if (prep_forked) WN_HIP_CHECK(hipStreamWaitEvent(s, exs.ev_fjoin, 0));   // the fold's images and biases are ready
   // skip sum folded into one contraction over all blocks' gated activations (src/model.py:235-236
   // with src/layers.py:216-219), or the last block output when use_skip is False
   const float* hin;

@@ -147,6 +147,8 @@ void exec_release(wn_exec* e) {
   if (e->d_pairs) (void)hipFree(e->d_pairs);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_ffork) (void)hipEventDestroy(e->ev_ffork);
+  if (e->ev_fjoin) (void)hipEventDestroy(e->ev_fjoin);
   if (e->side) (void)hipStreamDestroy(e->side);
   if (e->d_gen) (void)hipFree(e->d_gen);
   if (g_bound_exec == e) g_bound_exec = nullptr;

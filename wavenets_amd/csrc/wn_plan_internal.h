@@ -92,6 +92,7 @@ struct wn_exec {
   // side stream: the low-occupancy generic weight-gradient jobs overlap the per-block / skip kernels
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_ffork = nullptr, ev_fjoin = nullptr;   // forward pass: the fold's weight preparation beside the block chain
   int head_first = 0, cov_head_first = 0;   // job / coverage tables: the head's entries come last
   WnGenBlock* d_gen = nullptr;  // fused generation step: per-block offsets for one batch size
   WnGenBlock gen_blk0[3]{};
