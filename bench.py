@@ -165,7 +165,7 @@ def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmu
   """Train-step time and SURVEY 8(d) stack fraction of BASELINE configs[0], [3], [4] on one GPU (same step as the
   headline: Adam + clipnorm + the MSE metric's sample draw).  Host-timed between two device synchronisations."""
   import torch
-  from wavenets_amd import WaveNet, Adam, MeanSquaredError
+  from wavenets_amd import WaveNet, Adam, MeanSquaredError, _lib
   from wavenets_amd.data import synthetic_waveforms
   res = {}
   T_default = T
@@ -198,7 +198,7 @@ def other_configs_leg(dev, stack_profile, T: int = 16000, steps: int = 10, warmu
     R = kw['channels']
     S_eff = kw.get('skip_channels') or R
     stack_bytes = nblk * 4.0 * B * T * (2 * R + S_eff)
-    t_stack = stack_ms + (prep_ms if L.wn_debug_value(9) == 1 else 0.0)   # (prep runs beside the chain unless knob 9)
+    t_stack = stack_ms + (prep_ms if _lib.lib().wn_debug_value(9) == 1 else 0.0)   # (prep runs beside the chain unless knob 9)
     res[name] = {'workload': desc, 'kernel_families': m.kernel_report(), 'ms_per_step': dt * 1e3, 'samples_per_s': B * T / dt, 'steps': steps,
                  'ms_per_step_blocks': blocks_ms,
                  'final_loss': logs['loss'],
