@@ -494,6 +494,9 @@ __global__ __launch_bounds__(512, 2) void wn_gen_relay128_kernel(WnGen128Args a)
   // 4 z ready, 5 output handed on (wave 0); 6 skip accumulator arrived, 7 handed on (wave 4)
 #define RL_TS(w, k) do { if (a.ts && tile == 0 && tid == 64 * (w)) a.ts[b * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   RL_TS(0, 0);
+  // waves 0..3 carry the rows (the chain's critical path) through the 1x1 and share their SIMDs' matrix pipes with the skip
+  // waves 4..7, whose accumulator has a block's worth of slack: issue priority to waves 0..3 (as in wn_gen_chain3_kernel)
+  if (wave < 4) __builtin_amdgcn_s_setprio(3);
   if (tid == 0) x_sent = 0;                            // (visible after the first barrier; first read far behind it)
   const WnGenBlock g = a.blocks[b];
   // granule areas of this workgroup's INPUT (written by block b - 1) and OUTPUT (read by block b + 1)
