@@ -139,6 +139,11 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
 #pragma unroll
       for (int q = 0; q < QR; ++q) xq[tap][q] = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
     }
+    // the per-utterance conditioning bias: ONE coalesced request per lane (2 D floats a row) in the same round trip as the
+    // activations, spread to the accumulator layout through the wave's (still idle) output stage.  (As 16 D-layout loads
+    // behind the pin it cost a second, exposed round trip per tile: 38.8 against 34.5 us a launch with global conditioning.)
+    f32x4 cbv = {0.f, 0.f, 0.f, 0.f};
+    if (a.cb && 4 * lane < 2 * D) cbv = *reinterpret_cast<const f32x4*>(a.cb + (int64_t)b * 2 * D + 4 * lane);
     // Pin the requests HERE.  Without it hipcc's scheduler sinks most of them into the conv below, each right in front of its
     // first use with s_waitcnt vmcnt(0) behind it (to shorten the live ranges of the 2 * R / 8 quads): the conv then walks
     // six exposed global round trips per tile (found with s_memtime stamps: 8.1 k clocks for 96 MFMAs).
@@ -153,12 +158,13 @@ __global__ __launch_bounds__(512, 2) void wn_layer_fwd_f16_kernel(WnLayerFwdArgs
         u[j][4 * rq + 0] = bv.x; u[j][4 * rq + 1] = bv.y; u[j][4 * rq + 2] = bv.z; u[j][4 * rq + 3] = bv.w;
       }
     if (a.cb) {   // wave-uniform
-      const float* cbp = a.cb + (int64_t)b * 2 * D + 4 * h;
+      f32x4* cbl = reinterpret_cast<f32x4*>(stage);
+      if (4 * lane < 2 * D) cbl[lane] = cbv;
 #pragma unroll
       for (int j = 0; j < JU; ++j)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-          const f32x4 cv = *reinterpret_cast<const f32x4*>(cbp + 32 * j + 8 * rq);
+          const f32x4 cv = cbl[8 * j + 2 * rq + h];      // floats 32 j + 8 rq + 4 h ..
           u[j][4 * rq + 0] += cv.x; u[j][4 * rq + 1] += cv.y; u[j][4 * rq + 2] += cv.z; u[j][4 * rq + 3] += cv.w;
         }
     }
